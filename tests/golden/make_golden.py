@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by CALLING the real reference.
+
+Runs in the build container only (needs /root/reference and the scratch build made by
+oracle/build_ref.py, default /tmp/pygemma_ref).  What is committed is data: inputs and the
+reference's outputs (+ the versions that produced them).  No reference source is copied.
+
+    python oracle/build_ref.py && python tests/golden/make_golden.py
+"""
+import io
+import contextlib
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("PYGEMMA_REF", "/tmp/pygemma_ref")
+sys.path.insert(0, REF)
+
+warnings.filterwarnings("ignore")
+with contextlib.redirect_stdout(io.StringIO()):
+    from pygemma import lmm as ref  # the real reference  # noqa: E402
+import scipy  # noqa: E402
+import scipy.optimize  # noqa: E402
+import scipy.stats  # noqa: E402
+import pandas  # noqa: E402
+import Cython  # noqa: E402
+
+from pygemma_amd import synth  # noqa: E402
+
+VERS = np.array([f"numpy {np.__version__}", f"scipy {scipy.__version__}", f"pandas {pandas.__version__}",
+                 f"cython {Cython.__version__}", "reference rlangefe/pygemma @ 2024-11-15"])
+
+LAMS = [1e-5, 1e-3, 0.2, 5.0, 400.0, 1e3, 1e5]  # tests/test_pygemma.py:253 + the search boundaries
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        return fn(*a, **k)
+
+
+def defined_mask(m):
+    """[row, level, col] entries precompute_mat defines: row >= col >= level... i.e. the lower
+    triangle of block [i:, i, i:] (the rest is np.empty garbage / never-written upper part)."""
+    msk = np.zeros((m, m, m), bool)
+    for lvl in range(m):
+        for r in range(lvl, m):
+            for c in range(lvl, r + 1):
+                msk[r, lvl, c] = True
+    return msk
+
+
+def gen_precompute():
+    out = {"versions": VERS, "lams": np.array(LAMS, np.float32)}
+    cases = [(64, 1), (64, 5), (200, 10), (500, 5)]
+    out["cases"] = np.array(cases)
+    for ci, (n, c) in enumerate(cases):
+        rp = synth.rotated_panel(n, 3, c, seed=1000 + ci)
+        d, Wx, y = rp["d"], np.ascontiguousarray(np.c_[rp["W"], rp["X"][:, 0]]), rp["Y"]
+        out[f"c{ci}_d"], out[f"c{ci}_Wx"], out[f"c{ci}_y"] = d, Wx, y
+        m = Wx.shape[1] + 1
+        msk = defined_mask(m)
+        for li, lam in enumerate(LAMS):
+            for full in (0, 1):
+                r = quiet(ref.precompute_mat, lam, d, Wx, y, full=bool(full))
+                key = f"c{ci}_l{li}_f{full}_"
+                P3 = np.where(msk, r["wjt_Pi_wk"], np.nan).astype(np.float32)
+                out[key + "P3"] = P3
+                out[key + "Q3"] = np.where(msk[:m - 1, :, :m - 1], r["wjt_Pi_Pi_wk"], np.nan).astype(np.float32)
+                out[key + "yPy"], out[key + "yPPy"], out[key + "trP"] = r["yt_Pi_y"], r["yt_Pi_Pi_y"], r["tr_Pi"]
+                out[key + "ld"] = np.float32(r["logdet_Wt_H_inv_W"])
+                out[key + "ldH"] = np.float32(r["logdet_H"])
+                ctot = m - 1
+                if full:
+                    out[key + "R3"] = np.where(msk[:m - 1, :, :m - 1], r["wjt_Pi_Pi_Pi_wk"], np.nan).astype(np.float32)
+                    out[key + "yPPPy"], out[key + "trPP"] = r["yt_Pi_Pi_Pi_y"], r["tr_Pi_Pi"]
+                    out[key + "d2"] = np.float32(ref.likelihood_derivative2_restricted_lambda_overload(
+                        lam, n, ctot, r["yt_Pi_y"][ctot], r["yt_Pi_Pi_y"][ctot], r["yt_Pi_Pi_Pi_y"][ctot],
+                        r["tr_Pi"][ctot], r["tr_Pi_Pi"][ctot]))
+                out[key + "d1"] = np.float32(ref.likelihood_derivative1_restricted_lambda_overload(
+                    lam, n, ctot, r["yt_Pi_y"][ctot], r["yt_Pi_Pi_y"][ctot], r["tr_Pi"][ctot]))
+                out[key + "logl"] = np.float32(ref.likelihood_restricted_lambda_overload(
+                    lam, n, ctot, r["yt_Pi_y"][ctot], r["logdet_H"], r["logdet_Wt_W"], r["logdet_Wt_H_inv_W"]))
+    np.savez_compressed(os.path.join(HERE, "precompute_mat.npz"), **out)
+    print("precompute_mat.npz", len(out), "arrays")
+
+
+def run_panel(name, n, p, c, seed, null, extra=None, h2=0.5):
+    rp = synth.rotated_panel(n, p, c, seed=seed, null=null, h2=h2)
+    d, X, Y, W = rp["d"], rp["X"], rp["Y"], rp["W"]
+    out = {"versions": VERS, "d": d, "X": X, "Y": Y, "W": W}
+    for grid in (False, True):
+        df = quiet(ref.pygemma, Y, X, W, d, snps=[f"rs{i}" for i in range(p)], grid=grid, eigen=False, nproc=1)
+        tag = "grid" if grid else "brent"
+        assert list(df.columns) == ["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald", "SNPs"], df.columns
+        for col in ["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"]:
+            out[f"{tag}_{col}"] = df[col].to_numpy()
+        out[f"{tag}_dtypes"] = np.array([str(t) for t in df.dtypes])
+        # calc_lambda_restricted alone (pyx:64)
+        lam = np.array([quiet(ref.calc_lambda_restricted, d, Y, np.ascontiguousarray(np.c_[W, X[:, g]]), grid=grid)
+                        for g in range(p)], np.float64)
+        out[f"{tag}_calc_lambda"] = lam
+    # wrapper d1 on the decade grid and newton from the decade mid-points, first 40 SNPs (pyx:1631, pyx:1349)
+    ks = np.arange(-5, 6)
+    g40 = min(p, 40)
+    d1tab = np.zeros((g40, ks.size), np.float32)
+    nwt = np.zeros((g40, 10), np.float32)
+    for g in range(g40):
+        Wx = np.ascontiguousarray(np.c_[W, X[:, g]])
+        for j, k in enumerate(ks):
+            lam = np.float32(10.0 ** float(k))
+            d1tab[g, j] = ref.wrapper_likelihood_derivative1_restricted_lambda(lam, d, Y, Wx)
+        for j, k in enumerate(ks[:-1]):
+            l0, l1 = np.float32(10.0 ** float(k)), np.float32(10.0 ** float(k + 1))
+            start = np.float32(3.0) * l0
+            nwt[g, j] = quiet(ref.newton, start, d, Y, Wx, precompute=True, lambda_min=l0, lambda_max=l1)
+    out["d1_decades"], out["newton_from_3e_k"] = d1tab, nwt
+    if extra:
+        out.update(extra)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    nb = (out["brent_lambda"] <= 1.0001e-5).sum(), (out["brent_lambda"] >= 9.999e4).sum()
+    print(name, "n,p,c =", n, p, c, "boundary-lambda rows (lo,hi):", nb)
+
+
+def gen_brentq_fuzz():
+    rng = np.random.default_rng(7)
+    rows = []
+    # family: f(x) = a3 (x-r)^3 + a1 (x-r) + a0*sin(w x) evaluated at float32(x), result float32 (as at pyx:1631)
+    for t in range(400):
+        k = rng.integers(-5, 5)
+        a, b = 10.0 ** k, 10.0 ** (k + 1)
+        r = a + (b - a) * rng.uniform(0.01, 0.99)
+        a3, a1, a0, w = rng.uniform(-2, 2), rng.uniform(0.1, 3), rng.uniform(-0.05, 0.05), rng.uniform(0.1, 20)
+        sgn = rng.choice([-1.0, 1.0])
+
+        def f(x, a3=a3, a1=a1, a0=a0, w=w, r=r, sgn=sgn, s=(b - a)):
+            x = np.float32(x)
+            u = (np.float64(x) - r) / s
+            return float(np.float32(sgn * (a3 * u ** 3 + a1 * u + a0 * np.sin(w * u))))
+        if f(a) * f(b) >= 0:
+            continue
+        root, info = scipy.optimize.brentq(f, a, b, rtol=0.1, maxiter=100, full_output=True, disp=False)
+        rows.append([a, b, r, a3, a1, a0, w, sgn, root, info.function_calls, info.iterations])
+    np.savez_compressed(os.path.join(HERE, "brentq_fuzz.npz"), versions=VERS, rows=np.array(rows, np.float64),
+                        columns=np.array("a b r a3 a1 a0 w sgn root funcalls iterations".split()))
+    print("brentq_fuzz.npz", len(rows), "cases")
+
+
+def gen_fdist():
+    F = np.concatenate([[0.0, 1e-300, 1e-12, 1e-6], np.logspace(-4, 3.5, 160), [5e3, 2e4, 1e5]])
+    dfd = np.array([3.0, 10.0, 57.0, 292.0, 394.0, 1938.0, 1994.0, 9994.0, 9989.0, 49994.0])
+    FF, DD = np.meshgrid(F, dfd, indexing="ij")
+    sf = scipy.stats.f.sf(FF, 1, DD)
+    np.savez_compressed(os.path.join(HERE, "fdist_sf.npz"), versions=VERS, F=FF, dfd=DD, sf=sf)
+    print("fdist_sf.npz", sf.shape, "min p", sf[sf > 0].min())
+
+
+def gen_nplog():
+    rng = np.random.default_rng(3)
+    x = np.concatenate([np.exp(rng.uniform(0, 16, 200000)), np.linspace(1, 3, 50000)]).astype(np.float32)
+    ns = [1, 7, 8, 9, 63, 64, 127, 128, 129, 255, 256, 257, 1000, 1940, 2000, 4097, 10000, 50000]
+    sums = np.array([np.log(x[:k]).sum() for k in ns], np.float32)
+    np.savez_compressed(os.path.join(HERE, "np_log_f32.npz"), versions=VERS, x=x[:60000], logx=np.log(x[:60000]),
+                        ns=np.array(ns), sums=sums, xsum=x[:50000])
+    print("np_log_f32.npz")
+
+
+def gen_eigen_true():
+    """Tier C fixture: a full eigen=True run of the reference (float32 eigh + sgemm inside)."""
+    n, p, c = 300, 120, 3
+    raw = synth.panel(n, p, c, seed=4242)
+    out = {"versions": VERS, **raw}
+    for grid in (False, True):
+        df = quiet(ref.pygemma, raw["Y"], raw["X"], raw["W"], raw["K"], grid=grid, eigen=True, nproc=1)
+        for col in ["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"]:
+            out[("grid_" if grid else "brent_") + col] = df[col].to_numpy()
+    np.savez_compressed(os.path.join(HERE, "eigen_true_n300.npz"), **out)
+    print("eigen_true_n300.npz")
+
+
+def gen_mouse():
+    """config #1 shape: real phenotype column of data/mouse_hs1940.pheno.txt (NA -> mean, as
+    experiments/animal_gwas/run_gwas.py:83), SYNTHETIC genotypes / K (the real ones are not bundled,
+    .MISSING_LARGE_BLOBS), intercept-only W.  A 48-SNP slice keeps the fixture small."""
+    ph = np.genfromtxt("/root/reference/data/mouse_hs1940.pheno.txt", missing_values="NA", filling_values=np.nan)
+    y = ph[:, 0].copy()
+    y[np.isnan(y)] = np.nanmean(y)
+    n = y.size
+    raw = synth.panel(n, 48, 1, seed=1940)
+    d, U = np.linalg.eigh(raw["K"].astype(np.float64))
+    d = np.maximum(d, 0).astype(np.float32)
+    rot = lambda A: (U.T @ A.astype(np.float64)).astype(np.float32)
+    Xr, Yr, Wr = rot(raw["X"]), rot(y.reshape(-1, 1)), rot(raw["W"])
+    out = {"versions": VERS, "d": d, "X": Xr, "Y": Yr, "W": Wr, "y_raw": y.astype(np.float32)}
+    for grid in (False, True):
+        df = quiet(ref.pygemma, Yr, Xr, Wr, d, grid=grid, eigen=False, nproc=1)
+        for col in ["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"]:
+            out[("grid_" if grid else "brent_") + col] = df[col].to_numpy()
+    np.savez_compressed(os.path.join(HERE, "mouse_hs1940_synthG.npz"), **out)
+    print("mouse_hs1940_synthG.npz n =", n)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["precompute", "panels", "brentq", "fdist", "nplog", "eigen", "mouse"]
+    if "precompute" in which:
+        gen_precompute()
+    if "panels" in which:
+        run_panel("panel_signal_n400_c5.npz", 400, 300, 5, seed=11, null=False)
+        run_panel("panel_null_n400_c5.npz", 400, 300, 5, seed=12, null=True)
+        run_panel("panel_signal_n257_c1.npz", 257, 120, 1, seed=13, null=False)
+        run_panel("panel_null_n320_c10.npz", 320, 120, 10, seed=14, null=True)
+        run_panel("panel_weak_n300_c3.npz", 300, 200, 3, seed=15, null=False, h2=0.04)
+    if "brentq" in which:
+        gen_brentq_fuzz()
+    if "fdist" in which:
+        gen_fdist()
+    if "nplog" in which:
+        gen_nplog()
+    if "eigen" in which:
+        gen_eigen_true()
+    if "mouse" in which:
+        gen_mouse()
