@@ -1,0 +1,101 @@
+/*
+ * pygemma_hip.h — C ABI of the MI355X-native pyGEMMA hot path (libpygemma_hip.so).
+ *
+ * The reference (rlangefe/pygemma) has NO C ABI: its operator boundary is the Python call
+ * calculate((eigenVals, Y, W, X_block, grid)) -> list[dict]  (lmm/lmm.py:461-495) plus two
+ * third-party calls, scipy.linalg.eigh(K) (lmm/lmm.py:152,197) and U.T @ X (lmm/lmm.py:244-246).
+ * This header DEFINES the boundary a maintainer would bind with ctypes (INTEGRATION.md shows the
+ * stub).  Plain C: pointers + sizes, no C++/torch types.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative PG_E* code on failure; never throws, never
+ *    calls exit(); pg_last_error() returns a thread-local message for the last failure.
+ *  - "_dev" entry points take DEVICE pointers (hipMalloc'd, or torch tensors' data_ptr()) and
+ *    enqueue on the context's stream; they return after enqueueing (call pg_ctx_sync).
+ *    Entry points without "_dev" take HOST pointers, copy in/out and return when done.
+ *  - the caller owns every buffer it passes; the library owns only what hangs off pg_ctx.
+ *  - layouts: "SNP-major" Xr[g*ldx + i] (row g = rotated genotype vector of SNP g, ldx >= n);
+ *    "reference layout" X[i*p + g] (NumPy C-order (n,p), lmm/lmm.py:121-122).
+ */
+#ifndef PYGEMMA_HIP_H
+#define PYGEMMA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_OK 0
+#define PG_EINVAL (-22)     /* bad argument (shape, NULL, unsupported c)               */
+#define PG_ENOMEM (-12)     /* device allocation failed                                */
+#define PG_EHIP (-5)        /* a HIP runtime call or kernel launch failed               */
+#define PG_ENOTSUP (-95)    /* configuration not supported by this build                */
+#define PG_ENODEV (-19)     /* no usable GPU                                            */
+
+#define PG_MAX_COVARIATES 12 /* c supported by the register-resident Gram kernels        */
+
+typedef struct pg_ctx pg_ctx; /* one per (process, GPU): device id, stream, scratch      */
+
+const char *pg_last_error(void);
+const char *pg_version(void);
+int pg_device_count(void);                      /* GPUs visible to HIP (0 if none)       */
+int pg_ctx_create(int device, pg_ctx **out);    /* binds a device, creates a stream       */
+int pg_ctx_create_on_stream(int device, void *hip_stream, pg_ctx **out); /* caller's stream */
+void pg_ctx_destroy(pg_ctx *ctx);
+int pg_ctx_sync(pg_ctx *ctx);
+int pg_ctx_device(const pg_ctx *ctx);
+
+/* device memory helpers for callers without their own allocator (Python/ctypes hosts) */
+int pg_malloc(pg_ctx *ctx, size_t bytes, void **dptr);
+int pg_free(pg_ctx *ctx, void *dptr);
+int pg_memcpy_h2d(pg_ctx *ctx, void *dst, const void *src, size_t bytes);
+int pg_memcpy_d2h(pg_ctx *ctx, void *dst, const void *src, size_t bytes);
+int pg_memset(pg_ctx *ctx, void *dst, int value, size_t bytes);
+
+/* ---- H3-H10: the per-SNP operator -------------------------------------------------------
+ * Replaces calculate() (lmm/lmm.py:461-495) and everything under it: calc_lambda_restricted
+ * (pygemma_model.pyx:64-194, grid :99-132 / decade-scan+brentq+newton :135-194), precompute_mat
+ * (:880-1053), newton (:1349-1416), the *_overload scalars (:1656-1698, :1813-1830),
+ * calc_beta_vg_ve_restricted_overload (:1514-1537) and scipy.stats.f.sf (lmm/lmm.py:482).
+ *
+ * Inputs are in the eigenbasis (the reference's eigen=False boundary, lmm/lmm.py:164-167):
+ *   d   (n)      eigenvalues, already clamped >= 0
+ *   Wr  (n x c)  rotated covariates, row-major (NumPy C-order)
+ *   yr  (n)      rotated phenotype
+ *   Xr  (p rows) rotated genotypes, SNP-major, row stride ldx >= n
+ * Outputs (length p, caller-allocated, SNP order preserved): beta, se_beta, tau, lambda as
+ * float32; F_wald, p_wald as float64 (lmm/lmm.py:476-483; lambda is the f32 value the reference
+ * widens to a Python float).  pval may be NULL.  grid != 0 selects calc_lambda_restricted's grid
+ * branch.  stats (may be NULL) receives [fast evaluations, full (Newton) evaluations] summed over SNPs.
+ */
+int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
+                 const float *Xr, int64_t ldx, int grid, float *beta, float *se, float *tau, float *lambda,
+                 double *F, double *pval, unsigned long long *stats_dev);
+
+/* host-pointer convenience: X in the REFERENCE layout (n x p row-major, already rotated), as
+ * calculate() receives it; transposed to SNP-major on the device. */
+int pg_assoc(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
+             const float *X_n_by_p, int grid, float *beta, float *se, float *tau, float *lambda, double *F,
+             double *pval, unsigned long long *stats2);
+
+/* scipy.stats.f.sf(F, 1, dfd) (lmm/lmm.py:482) for a device vector */
+int pg_fdist_sf_dev(pg_ctx *ctx, int64_t count, const double *F, double dfd, double *pval);
+
+/* (n x p row-major) -> SNP-major (p x ldx), pad columns [n, ldx) zero-filled */
+int pg_transpose_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *X_n_by_p, float *Xr, int64_t ldx);
+
+/* ---- H2: rotation  X <- U' X  (lmm/lmm.py:243-246, OpenBLAS sgemm in the reference) ---------
+ * U (n x n) row-major with eigenvector j in COLUMN j (scipy.linalg.eigh's convention); X in the
+ * reference layout (n x p); output SNP-major Xr (p x ldx): Xr[g*ldx + k] = sum_i U[i*n + k] * X[i*p + g].
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate — the reference's own precision. */
+int pg_rotate_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, const float *X_n_by_p, float *Xr, int64_t ldx);
+
+/* ---- H1: eigendecomposition of K (lmm/lmm.py:151-162 / :196-207, scipy.linalg.eigh = LAPACK ssyevr)
+ * Reads the LOWER triangle of row-major K (n x n, float32, device).  Computes in fp64; delivers ascending
+ * eigenvalues clamped at 0 (lmm/lmm.py:157) as float32, and U (column j = eigenvector j) as float32
+ * (and optionally fp64 for the invariant checks: U64/evals64 may be NULL). */
+int pg_syevd_dev(pg_ctx *ctx, int64_t n, const float *K, float *evals, float *U, double *evals64, double *U64);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYGEMMA_HIP_H */

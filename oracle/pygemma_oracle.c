@@ -210,10 +210,10 @@ static void gram0_seq(float lam, const float *d, const float *const *cols, long 
 /* The HIP kernels' order: lane l of a 64-wide wavefront accumulates i = l, l+64, ...;
  * products are a_j = h*w_j (exact in f64), g_j = (h*h)*w_j; P_jk = fma(a_j, w_k, P_jk),
  * Q_jk = fma(a_j, a_k, Q_jk), R_jk = fma(g_j, a_k, R_jk) for row j >= col k;
- * t1 += h, t2 = fma(h,h,t2); then v += shfl_xor(v, s) for s = 32,16,8,4,2,1. */
+ * t1 += h, t2 = fma(h,h,t2); then v += shfl_xor(v, s) for s = 1,2,4,8,16,32. */
 static double butterfly64(double *v)
 {
-    for (int s = 32; s >= 1; s >>= 1) {
+    for (int s = 1; s < 64; s <<= 1) {
         double t[64];
         for (int l = 0; l < 64; l++) t[l] = v[l] + v[l ^ s];
         memcpy(v, t, sizeof(t));

@@ -1,0 +1,143 @@
+"""ctypes binding of libpygemma_hip.so (C ABI: include/pygemma_hip.h).
+
+The MI355X path has NO CPU fallback: if the shared library is missing or no GPU is visible the
+calls raise.  This module never imports anything from oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpygemma_hip.so")
+_lib = None
+
+SYMBOLS = [
+    "pg_last_error", "pg_version", "pg_device_count", "pg_ctx_create", "pg_ctx_create_on_stream",
+    "pg_ctx_destroy", "pg_ctx_sync", "pg_ctx_device", "pg_malloc", "pg_free", "pg_memcpy_h2d", "pg_memcpy_d2h",
+    "pg_memset", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev", "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev",
+]
+
+
+class PgError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (build it first with __graft_entry__.build() / make -C pygemma_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PgError(f"{LIB_PATH} not found: build the HIP extension (python -c 'import __graft_entry__ as g; g.build()'). "
+                      "pygemma_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
+    L.pg_last_error.restype = C.c_char_p
+    L.pg_version.restype = C.c_char_p
+    L.pg_device_count.restype = i32
+    L.pg_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.pg_ctx_create_on_stream.argtypes = [i32, vp, C.POINTER(vp)]
+    L.pg_ctx_destroy.argtypes = [vp]
+    L.pg_ctx_destroy.restype = None
+    L.pg_ctx_sync.argtypes = [vp]
+    L.pg_ctx_device.argtypes = [vp]
+    L.pg_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.pg_free.argtypes = [vp, vp]
+    L.pg_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    L.pg_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    L.pg_memset.argtypes = [vp, vp, i32, sz]
+    L.pg_assoc_dev.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.pg_assoc.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.pg_fdist_sf_dev.argtypes = [vp, i64, vp, C.c_double, vp]
+    L.pg_transpose_dev.argtypes = [vp, i64, i64, vp, vp, i64]
+    L.pg_rotate_dev.argtypes = [vp, i64, i64, vp, vp, vp, i64]
+    L.pg_syevd_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    for name in ("pg_ctx_create", "pg_ctx_create_on_stream", "pg_ctx_sync", "pg_ctx_device", "pg_malloc", "pg_free",
+                 "pg_memcpy_h2d", "pg_memcpy_d2h", "pg_memset", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev",
+                 "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev"):
+        getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise PgError(f"{what} failed (code {rc}): {load().pg_last_error().decode()}")
+
+
+class DeviceBuffer:
+    """hipMalloc'd buffer owned by a Context (freed with it or by .free())."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        check(load().pg_malloc(ctx.handle, self.nbytes, C.byref(p)), "pg_malloc")
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            load().pg_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(load().pg_memcpy_h2d(self.ctx.handle, self.ptr, arr.ctypes.data, arr.nbytes), "pg_memcpy_h2d")
+        return self
+
+    def download(self, shape, dtype, offset=0):
+        out = np.empty(shape, dtype)
+        check(load().pg_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr + offset, out.nbytes), "pg_memcpy_d2h")
+        return out
+
+
+class Context:
+    """One per (process, GPU): wraps pg_ctx (device id + stream + scratch)."""
+
+    def __init__(self, device=0, stream=None):
+        L = load()
+        h = C.c_void_p()
+        if stream is None:
+            check(L.pg_ctx_create(int(device), C.byref(h)), "pg_ctx_create")
+        else:
+            check(L.pg_ctx_create_on_stream(int(device), C.c_void_p(stream), C.byref(h)), "pg_ctx_create_on_stream")
+        self.handle = h
+        self.device = device
+        self._bufs = []
+
+    def alloc(self, nbytes):
+        b = DeviceBuffer(self, nbytes)
+        self._bufs.append(b)
+        return b
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return self.alloc(max(arr.nbytes, 4)).upload(arr)
+
+    def sync(self):
+        check(load().pg_ctx_sync(self.handle), "pg_ctx_sync")
+
+    def close(self):
+        if self.handle:
+            for b in self._bufs:
+                b.free()
+            self._bufs = []
+            load().pg_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_count():
+    return load().pg_device_count()

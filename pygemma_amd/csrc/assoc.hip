@@ -1,0 +1,731 @@
+// assoc.hip — the per-SNP LMM association operator on gfx950 (MI355X).
+//
+// Replaces, per SNP g, everything under calculate() in the reference (lmm/lmm.py:461-495):
+//   calc_lambda_restricted (pygemma_model.pyx:64-194) -> precompute_mat (:880-1053), newton (:1349-1416),
+//   scipy.optimize.brentq (:176-182), the *_overload scalars (:1656-1698, :1813-1830),
+//   calc_beta_vg_ve_restricted_overload (:1514-1537), F = (beta/se)^2 and scipy.stats.f.sf (lmm.py:471,482).
+//
+// Mapping: ONE 64-lane wavefront per SNP.  Lane l owns elements i = l, l+64, ... of the n-vectors
+// (coalesced reads of the SNP-major genotype row and of the packed fixed rows {d_i, w_i*, y_i});
+// every Gram entry is a per-lane fma chain followed by a 64-lane xor-butterfly (strides 1,2,..,32),
+// so all lanes hold the same f64 sums and run the O(m^3) sweeps / Brent / Newton logic uniformly.
+// Precision follows SURVEY.md Appendix A: h = 1/(lam*d+1) in three separately rounded f32 ops,
+// Grams and sweeps in f64, every exported quadratic form rounded to f32, f32 lambda iterates.
+// The arithmetic order is mirrored exactly by oracle/pygemma_oracle.c (order=1) so that GPU and
+// oracle agree bit-for-bit; compile with -ffp-contract=off (every fma below is explicit).
+//
+// What is shared between SNPs is hoisted: the decade lambdas 10^-5..10^5 are the same for every SNP,
+// so h tables, the SNP-independent Gram entries (W,y block), trace terms and log|H| at those 11
+// lambdas are computed once (setup kernel); per SNP the scan only accumulates the 2(c+2) entries
+// that involve x.  Evaluations at SNP-specific lambdas (Brent, Newton, final) need the full Grams.
+#include "common.hpp"
+
+#include <cmath>
+
+namespace pg {
+
+constexpr int NLAM = 11;  // decade lambdas 10^-5 .. 10^5
+constexpr int WPB = 4;    // wavefronts (= SNPs) per workgroup
+#define PG_MINV 1e-35f    // pygemma_model.pyx:39
+
+struct AssocParams {
+    int n, npad, c, niter, nu, grid, rowf;  // nu = n - (c+1); rowf = floats per fixed row (multiple of 4)
+    long long p, ldx;
+    const float *xr;
+    const float *fixed;    // [npad][rowf]: d, w_0..w_{c-1}, y, zero pad; rows >= n all zero
+    float *htab;           // [NLAM][npad]   (0 for i >= n)
+    double *fixg;          // [NLAM][2][NP]  level-0 P,Q over all columns with x := 0
+    double *t1tab;         // [NLAM]
+    float *ldHtab;         // [NLAM]
+    float lam11[NLAM];
+    float logl_c;          // f32(f32(.5nu*ln(.5nu/pi)) - .5nu)   (pyx:1821-1822)
+    const int *leaf, *node, *level, *chunk;
+    int n_leaf, n_level, n_chunk, n_vals;
+    float *beta, *se, *tau, *lam;
+    double *F;
+    unsigned long long *stats;
+};
+
+struct EvalOut { float yPy, yPPy, yPPPy, trP, trPP, ld, Pxx_c, Pyx_c; };
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float hinv_f32(float lam, float d)
+{   // pyx:903  1.0/(lam*eigenVals + 1.0) on float32 arrays: three separately rounded f32 operations
+    return __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(lam, d), 1.0f));
+}
+
+// numpy's SIMD float32 log (see oracle/pygemma_oracle.c: orc_np_logf) — bit-exact restatement
+__device__ __forceinline__ float np_logf(float x)
+{
+    const float p1 = 9.999999999999998702752e-01f, p2 = 2.112677543073053063722e+00f,
+                p3 = 1.480000633576506585156e+00f, p4 = 3.808837741388407920751e-01f,
+                p5 = 2.589979117907922693523e-02f;
+    const float q1 = 2.612677543073109236779e+00f, q2 = 2.453006071784736363091e+00f,
+                q3 = 9.864942958519418960339e-01f, q4 = 1.546476374983906719538e-01f,
+                q5 = 5.875095403124574342950e-03f;
+    unsigned u = __float_as_uint(x);
+    int e = (int)((u >> 23) & 0xff) - 126;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
+    float ef = (float)e;
+    if (m <= 0.70710678118f) { m = __fadd_rn(m, m); ef = __fsub_rn(ef, 1.0f); }
+    float t = __fsub_rn(m, 1.0f);
+    float den = fmaf(q5, t, q4);
+    den = fmaf(den, t, q3); den = fmaf(den, t, q2); den = fmaf(den, t, q1); den = fmaf(den, t, 1.0f);
+    float num = fmaf(p5, t, p4);
+    num = fmaf(num, t, p3); num = fmaf(num, t, p2); num = fmaf(num, t, p1); num = fmaf(num, t, 0.0f);
+    float poly = __fdiv_rn(num, den);
+    return fmaf(ef, 0.693147180559945309417232121458176568f, poly);
+}
+
+__device__ __forceinline__ double bfly(double v)
+{
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+// log|H| = float(np.log(lam*eigenVals + 1.0).sum())  (pyx:972): numpy's float32 pairwise sum
+// (8-accumulator leaves of <= 128 elements, binary recursion, sequential across 8192-element
+// chunks) reproduced with the host-built plan: 8 lanes per leaf, tree levels in parallel.
+// vals: per-wave LDS scratch of n_vals floats.  All lanes return the same value.
+__device__ float device_logdet_H(const AssocParams &pr, float lam, int lane, float *vals)
+{
+    const int sub = lane & 7, grp = lane >> 3;
+    auto elem = [&](int i) -> float {
+        float d = pr.fixed[(size_t)i * pr.rowf];
+        return np_logf(__fadd_rn(__fmul_rn(lam, d), 1.0f));
+    };
+    for (int l0 = 0; l0 < pr.n_leaf; l0 += 8) {
+        const int lf = l0 + grp;
+        int start = 0, len = 0;
+        if (lf < pr.n_leaf) { start = pr.leaf[2 * lf]; len = pr.leaf[2 * lf + 1]; }
+        float res = 0.0f;
+        if (len >= 8) {
+            const int body = len - (len & 7);
+            float r = elem(start + sub);
+            for (int i = 8; i < body; i += 8) r = __fadd_rn(r, elem(start + i + sub));
+            // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) : xor butterfly inside the 8-lane group
+            r = __fadd_rn(r, __shfl_xor(r, 1, 64));
+            r = __fadd_rn(r, __shfl_xor(r, 2, 64));
+            r = __fadd_rn(r, __shfl_xor(r, 4, 64));
+            res = r;
+            for (int i = body; i < len; i++) res = __fadd_rn(res, elem(start + i));
+        } else {
+            // the shuffles above must be executed by whole groups only; groups are uniform in `len`
+            for (int i = 0; i < len; i++) res = __fadd_rn(res, elem(start + i));
+        }
+        if (lf < pr.n_leaf && sub == 0) vals[lf] = res;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int h = 0; h < pr.n_level; h++) {
+        const int b = pr.level[h], e = pr.level[h + 1];
+        for (int k = b + lane; k < e; k += 64) {
+            float a = vals[pr.node[2 * k]], c = vals[pr.node[2 * k + 1]];
+            vals[pr.n_leaf + k] = __fadd_rn(a, c);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    float tot = vals[pr.chunk[0]];
+    for (int k = 1; k < pr.n_chunk; k++) tot = __fadd_rn(tot, vals[pr.chunk[k]]);
+    return tot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar REML functions — same statements, same widths as the C Cython generates
+__device__ __forceinline__ float logl_f(const AssocParams &pr, float yPy, float ldH, float ld)
+{   // pyx:1813-1830 (first two statements folded into pr.logl_c on the host; logdet_Wt_W = 0.0)
+    float r = pr.logl_c;
+    r = (float)((double)r + (0.5 * (double)0.0f));
+    r = (float)((double)r - (0.5 * (double)ldH));
+    r = (float)((double)r - (0.5 * (double)ld));
+    r = (float)((double)r - ((0.5 * (double)pr.nu) * log((double)yPy)));
+    return r;
+}
+__device__ __forceinline__ float d1_f(const AssocParams &pr, float lam, float yPy, float yPPy, float trP)
+{   // pyx:1656-1669
+    float yT = (PG_MINV > yPy) ? PG_MINV : yPy;
+    float nc_tr = __fsub_rn((float)pr.nu, trP);
+    float r = (float)(-0.5 * (double)__fdiv_rn(nc_tr, lam));
+    float t = (0.0f > yPPy) ? 0.0f : yPPy;
+    float g = __fdiv_rn(__fsub_rn(yT, t), lam);
+    r = (float)((double)r + ((0.5 * (double)pr.nu) * (double)g) / (double)yT);
+    return r;
+}
+__device__ __forceinline__ float d2_f(const AssocParams &pr, float lam, float yPy, float yPPy, float yPPPy,
+                                      float trP, float trPP)
+{   // pyx:1675-1698
+    float a = (PG_MINV > yPy) ? PG_MINV : yPy;
+    float b = (PG_MINV > yPPy) ? PG_MINV : yPPy;
+    float e = (PG_MINV > yPPPy) ? PG_MINV : yPPPy;
+    double lam2 = (double)lam * (double)lam;           // pow(lam, 2.0): exact product of two f32
+    float ae = __fadd_rn(a, e);
+    float G2 = (float)(((double)ae - 2.0 * (double)b) / lam2);
+    float G1 = __fdiv_rn(__fsub_rn(a, b), lam);
+    float nct = __fadd_rn((float)pr.nu, trPP);
+    float r = (float)((0.5 * ((double)nct - 2.0 * (double)trP)) / lam2);
+    float G2a = __fmul_rn(G2, a);
+    r = (float)((double)r - ((double)pr.nu * ((double)G2a - (0.5 * (double)G1) * (double)G1)) / ((double)a * (double)a));
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int C> struct Shape {
+    static constexpr int M = C + 2;             // columns of W* = [W | x | y]
+    static constexpr int NP = M * (M + 1) / 2;  // lower-triangle entries
+};
+__host__ __device__ constexpr int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // r >= c
+
+__device__ __forceinline__ double dmaxf(double a, float b) { return ((double)b > a) ? (double)b : a; }
+
+// The c_tot sweeps of precompute_mat on register-resident lower triangles (pyx:947-963 / :1007-1036),
+// arithmetic identical to oracle sweeps(order=1).
+template <int M, bool FULL>
+__device__ __forceinline__ void sweeps(double *P, double *Q, double *R, double t1, double t2, EvalOut &o)
+{
+    P[0] = dmaxf(P[0], PG_MINV);
+    double trP = t1, trPP = t2;
+    float ld = 0.0f;
+    if (M - 2 == 0) { o.Pxx_c = (float)P[tri(M - 2, M - 2)]; o.Pyx_c = (float)P[tri(M - 1, M - 2)]; }
+#pragma unroll
+    for (int i = 1; i < M; i++) {
+        const int q = i - 1;
+        const double a = P[tri(q, q)], b = Q[tri(q, q)];
+        if (FULL) {
+            const double e = R[tri(q, q)];
+            double ba = b / a;
+            trPP = (trPP + ba * ba) - 2 * (e / a);
+            double a2 = a * a, a3 = a2 * a, b2 = b * b;
+            double cR = (e / a2) - (b2 / a3);
+            double ia = -1.0 / a, ba2 = b / a2;
+#pragma unroll
+            for (int r = i; r < M; r++)
+#pragma unroll
+                for (int c = i; c <= r; c++) {
+                    double ur = P[tri(r, q)], uc = P[tri(c, q)], vr = Q[tri(r, q)], vc = Q[tri(c, q)];
+                    double wr = R[tri(r, q)], wc = R[tri(c, q)];
+                    double s1 = fma(cR * uc, ur, R[tri(r, c)]);
+                    double s2 = fma(ia * uc, wr, 0.0); s2 = fma(ia * wc, ur, s2);
+                    double s3 = fma(ia * vc, vr, 0.0);
+                    double s4 = fma(ba2 * uc, vr, 0.0); s4 = fma(ba2 * vc, ur, s4);
+                    R[tri(r, c)] = ((s1 + s2) + s3) + s4;
+                }
+            R[tri(i, i)] = dmaxf(R[tri(i, i)], PG_MINV);
+        }
+        trP = trP - b / a;
+        {
+            double a2 = a * a;
+            double al1 = b / a2, ia = -1.0 / a;
+#pragma unroll
+            for (int r = i; r < M; r++)
+#pragma unroll
+                for (int c = i; c <= r; c++) {
+                    double ur = P[tri(r, q)], uc = P[tri(c, q)], vr = Q[tri(r, q)], vc = Q[tri(c, q)];
+                    double s1 = fma(al1 * uc, ur, Q[tri(r, c)]);
+                    double s2 = fma(ia * uc, vr, 0.0); s2 = fma(ia * vc, ur, s2);
+                    Q[tri(r, c)] = s1 + s2;
+                }
+            Q[tri(i, i)] = dmaxf(Q[tri(i, i)], PG_MINV);
+        }
+        ld = (float)((double)ld + log(a));
+        {
+            double ia = -1.0 / a;
+#pragma unroll
+            for (int r = i; r < M; r++)
+#pragma unroll
+                for (int c = i; c <= r; c++) {
+                    double ur = P[tri(r, q)], uc = P[tri(c, q)];
+                    P[tri(r, c)] = fma(ia * uc, ur, P[tri(r, c)]);
+                }
+            P[tri(i, i)] = dmaxf(P[tri(i, i)], PG_MINV);
+        }
+        if (i == M - 2) { o.Pxx_c = (float)P[tri(M - 2, M - 2)]; o.Pyx_c = (float)P[tri(M - 1, M - 2)]; }
+    }
+    o.yPy = (float)P[tri(M - 1, M - 1)];
+    o.yPPy = (float)Q[tri(M - 1, M - 1)];
+    o.yPPPy = FULL ? (float)R[tri(M - 1, M - 1)] : 0.0f;
+    o.trP = (float)trP;
+    o.trPP = FULL ? (float)trPP : 0.0f;
+    o.ld = ld;
+}
+
+// load one packed fixed row (d, w_0..w_{C-1}, y) for element i as 16-byte vectors
+template <int C>
+__device__ __forceinline__ void load_row(const AssocParams &pr, int i, float &d, float (&col)[C + 2])
+{
+    constexpr int S4 = (C + 2 + 3) / 4;
+    float buf[4 * S4];
+    const float4 *src = reinterpret_cast<const float4 *>(pr.fixed + (size_t)i * pr.rowf);
+#pragma unroll
+    for (int k = 0; k < S4; k++) {
+        float4 v = src[k];
+        buf[4 * k] = v.x; buf[4 * k + 1] = v.y; buf[4 * k + 2] = v.z; buf[4 * k + 3] = v.w;
+    }
+    d = buf[0];
+#pragma unroll
+    for (int j = 0; j < C; j++) col[j] = buf[1 + j];
+    col[C + 1] = buf[C + 1];  // y; col[C] (= x) is filled by the caller
+}
+
+// Level-0 Grams at an arbitrary lambda: all (C+2)(C+3)/2 entries of P, Q [, R], t1 [, t2]; then the sweeps.
+template <int C, bool FULL>
+__device__ __forceinline__ void eval_specific(const AssocParams &pr, const float *xrow, float lam, int lane, EvalOut &o)
+{
+    constexpr int M = Shape<C>::M, NP = Shape<C>::NP;
+    double P[NP], Q[NP], R[FULL ? NP : 1];
+#pragma unroll
+    for (int k = 0; k < NP; k++) { P[k] = 0.0; Q[k] = 0.0; if (FULL) R[k] = 0.0; }
+    double t1 = 0.0, t2 = 0.0;
+    for (int it = 0; it < pr.niter; it++) {
+        const int i = it * 64 + lane;
+        float d, colf[M];
+        load_row<C>(pr, i, d, colf);
+        colf[C] = (xrow != nullptr && i < pr.n) ? xrow[i] : 0.0f;
+        const float h = (i < pr.n) ? hinv_f32(lam, d) : 0.0f;
+        const double hd = (double)h;
+        double col[M], a[M];
+#pragma unroll
+        for (int j = 0; j < M; j++) { col[j] = (double)colf[j]; a[j] = hd * col[j]; }
+#pragma unroll
+        for (int j = 0; j < M; j++)
+#pragma unroll
+            for (int k = 0; k <= j; k++) {
+                P[tri(j, k)] = fma(a[j], col[k], P[tri(j, k)]);
+                Q[tri(j, k)] = fma(a[j], a[k], Q[tri(j, k)]);
+            }
+        t1 += hd;
+        if (FULL) {
+            const double h2 = hd * hd;
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                const double gj = h2 * col[j];
+#pragma unroll
+                for (int k = 0; k <= j; k++) R[tri(j, k)] = fma(gj, a[k], R[tri(j, k)]);
+            }
+            t2 = fma(hd, hd, t2);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NP; k++) { P[k] = bfly(P[k]); Q[k] = bfly(Q[k]); if (FULL) R[k] = bfly(R[k]); }
+    t1 = bfly(t1);
+    if (FULL) t2 = bfly(t2);
+    sweeps<M, FULL>(P, Q, R, t1, t2, o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// setup: one wavefront per decade lambda t — h table, SNP-independent level-0 Gram entries (x := 0),
+// t1 and log|H| at lam11[t].
+template <int C>
+__global__ __launch_bounds__(64) void setup_tabs_kernel(AssocParams pr)
+{
+    constexpr int M = Shape<C>::M, NP = Shape<C>::NP;
+    extern __shared__ float smem_f[];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const float lam = pr.lam11[t];
+    double P[NP], Q[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) { P[k] = 0.0; Q[k] = 0.0; }
+    double t1 = 0.0;
+    for (int it = 0; it < pr.niter; it++) {
+        const int i = it * 64 + lane;
+        float d, colf[M];
+        load_row<C>(pr, i, d, colf);
+        colf[C] = 0.0f;
+        const float h = (i < pr.n) ? hinv_f32(lam, d) : 0.0f;
+        pr.htab[(size_t)t * pr.npad + i] = h;
+        const double hd = (double)h;
+        double col[M], a[M];
+#pragma unroll
+        for (int j = 0; j < M; j++) { col[j] = (double)colf[j]; a[j] = hd * col[j]; }
+#pragma unroll
+        for (int j = 0; j < M; j++)
+#pragma unroll
+            for (int k = 0; k <= j; k++) {
+                P[tri(j, k)] = fma(a[j], col[k], P[tri(j, k)]);
+                Q[tri(j, k)] = fma(a[j], a[k], Q[tri(j, k)]);
+            }
+        t1 += hd;
+    }
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        double pv = bfly(P[k]), qv = bfly(Q[k]);
+        if (lane == 0) { pr.fixg[((size_t)t * 2 + 0) * NP + k] = pv; pr.fixg[((size_t)t * 2 + 1) * NP + k] = qv; }
+    }
+    t1 = bfly(t1);
+    float ldH = device_logdet_H(pr, lam, lane, smem_f);
+    if (lane == 0) { pr.t1tab[t] = t1; pr.ldHtab[t] = ldH; }
+}
+
+// scan accumulation: only the Gram entries that involve x, for G decade lambdas at once
+template <int C, int G>
+__device__ __forceinline__ void scan_accumulate(const AssocParams &pr, const float *xrow, int t0, int lane, double *xent)
+{
+    constexpr int M = Shape<C>::M;
+    double acc[G][2 * M];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int k = 0; k < 2 * M; k++) acc[g][k] = 0.0;
+    for (int it = 0; it < pr.niter; it++) {
+        const int i = it * 64 + lane;
+        float d, colf[M];
+        load_row<C>(pr, i, d, colf);
+        colf[C] = (i < pr.n) ? xrow[i] : 0.0f;
+        double col[M];
+#pragma unroll
+        for (int j = 0; j < M; j++) col[j] = (double)colf[j];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const double hd = (double)pr.htab[(size_t)(t0 + g) * pr.npad + i];
+            double a[M];
+#pragma unroll
+            for (int j = 0; j < M; j++) a[j] = hd * col[j];
+            // row x (index C): columns k <= C ; row y (index C+1): column x
+#pragma unroll
+            for (int k = 0; k <= C; k++) {
+                acc[g][k] = fma(a[C], col[k], acc[g][k]);
+                acc[g][M + k] = fma(a[C], a[k], acc[g][M + k]);
+            }
+            acc[g][C + 1] = fma(a[C + 1], col[C], acc[g][C + 1]);
+            acc[g][M + C + 1] = fma(a[C + 1], a[C], acc[g][M + C + 1]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int k = 0; k < 2 * M; k++) xent[(t0 + g) * 2 * M + k] = bfly(acc[g][k]);  // every lane writes the same value
+}
+
+// scipy.optimize.brentq (scipy/optimize/Zeros/brentq.c), xtol=2e-12, rtol=0.1, maxiter=100 (pyx:176-182).
+// f(a), f(b) are the decade-scan values (the reference re-evaluates them: same inputs, same results).
+template <class Fn>
+__device__ __forceinline__ double brentq_dev(Fn &&f, double xa, double xb, double fa, double fb)
+{
+    const double xtol = 2e-12, rtol = 0.1;
+    double xpre = xa, xcur = xb, xblk = 0., fpre = fa, fcur = fb, fblk = 0., spre = 0., scur = 0., sbis, delta, stry, dpre, dblk;
+    if (fpre == 0) return xpre;
+    if (fcur == 0) return xcur;
+    for (int i = 0; i < 100; i++) {
+        if (fpre != 0 && fcur != 0 && (__builtin_signbit(fpre) != __builtin_signbit(fcur))) {
+            xblk = xpre; fblk = fpre; spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur; xcur = xblk; xblk = xpre;
+            fpre = fcur; fcur = fblk; fblk = fpre;
+        }
+        delta = (xtol + rtol * fabs(xcur)) / 2;
+        sbis = (xblk - xcur) / 2;
+        if (fcur == 0 || fabs(sbis) < delta) return xcur;
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                dpre = (fpre - fcur) / (xpre - xcur);
+                dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            double lim = 3 * fabs(sbis) - delta;
+            double mn = fabs(spre) < lim ? fabs(spre) : lim;
+            if (2 * fabs(stry) < mn) { spre = scur; scur = stry; }
+            else { spre = sbis; scur = sbis; }
+        } else { spre = sbis; scur = sbis; }
+        xpre = xcur; fpre = fcur;
+        if (fabs(scur) > delta) xcur += scur;
+        else xcur += (sbis > 0 ? delta : -delta);
+        fcur = f(xcur);
+    }
+    return xcur;
+}
+
+template <int C>
+__global__ __launch_bounds__(64 * WPB) void assoc_kernel(AssocParams pr)
+{
+    constexpr int M = Shape<C>::M, NP = Shape<C>::NP;
+    extern __shared__ unsigned char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long g = (long long)blockIdx.x * WPB + wave;
+    if (g >= pr.p) return;  // whole wavefront leaves; no workgroup barrier is used anywhere in this kernel
+    // per-wave LDS: xent[NLAM][2M] doubles | evs[NLAM] | d1s[NLAM] | lls[NLAM] | vals[n_vals]
+    const size_t per_wave = (size_t)NLAM * 2 * M * 8 + NLAM * sizeof(EvalOut) + 2 * NLAM * 4 + (size_t)pr.n_vals * 4;
+    unsigned char *base = smem + (size_t)wave * ((per_wave + 15) & ~(size_t)15);
+    double *xent = reinterpret_cast<double *>(base);
+    EvalOut *evs = reinterpret_cast<EvalOut *>(base + (size_t)NLAM * 2 * M * 8);
+    float *d1s = reinterpret_cast<float *>(evs + NLAM);
+    float *lls = d1s + NLAM;
+    float *vals = lls + NLAM;
+    const float *xrow = pr.xr + (size_t)g * pr.ldx;
+
+    // ---- decade scan: x-dependent Gram entries at the 11 shared lambdas
+    scan_accumulate<C, 4>(pr, xrow, 0, lane, xent);
+    scan_accumulate<C, 4>(pr, xrow, 4, lane, xent);
+    scan_accumulate<C, 3>(pr, xrow, 8, lane, xent);
+    for (int t = 0; t < NLAM; t++) {
+        double P[NP], Q[NP], Rdummy[1];
+        const double *fp = pr.fixg + ((size_t)t * 2 + 0) * NP, *fq = pr.fixg + ((size_t)t * 2 + 1) * NP;
+#pragma unroll
+        for (int k = 0; k < NP; k++) { P[k] = fp[k]; Q[k] = fq[k]; }
+        const double *xe = xent + t * 2 * M;
+#pragma unroll
+        for (int k = 0; k <= C; k++) { P[tri(C, k)] = xe[k]; Q[tri(C, k)] = xe[M + k]; }
+        P[tri(C + 1, C)] = xe[C + 1];
+        Q[tri(C + 1, C)] = xe[M + C + 1];
+        EvalOut e;
+        sweeps<M, false>(P, Q, Rdummy, pr.t1tab[t], 0.0, e);
+        evs[t] = e;
+        d1s[t] = d1_f(pr, pr.lam11[t], e.yPy, e.yPPy, e.trP);
+        lls[t] = logl_f(pr, e.yPy, pr.ldHtab[t], e.ld);
+    }
+    // ---- candidate selection (pyx:109-117 / :144-152): start from the two boundaries
+    float best_l = lls[0], best_lambda;
+    EvalOut best_e;
+    if (best_l < lls[NLAM - 1]) { best_l = lls[NLAM - 1]; best_lambda = pr.lam11[NLAM - 1]; best_e = evs[NLAM - 1]; }
+    else { best_lambda = pr.lam11[0]; best_e = evs[0]; }
+    unsigned n_fast = 0, n_full = 0;
+    if (pr.grid) {
+        for (int t = 0; t < NLAM - 1; t++)   // pyx:119-130, k = -5..4, strict '>'
+            if (lls[t] > best_l) { best_l = lls[t]; best_lambda = pr.lam11[t]; best_e = evs[t]; }
+    } else {
+        for (int k = 0; k < NLAM - 1; k++) {  // pyx:154-192
+            const float f0 = d1s[k], f1 = d1s[k + 1];
+            if (__builtin_signbit(f0) == __builtin_signbit(f1)) continue;   // copysignf product < 0 (pyx:174)
+            const float l0 = pr.lam11[k], l1 = pr.lam11[k + 1];
+            double root = brentq_dev(
+                [&](double x) -> double {
+                    EvalOut e;
+                    const float lf = (float)x;      // pyx:1631: np.float32_t lam
+                    eval_specific<C, false>(pr, xrow, lf, lane, e);
+                    n_fast++;
+                    return (double)d1_f(pr, lf, e.yPy, e.yPPy, e.trP);
+                },
+                (double)l0, (double)l1, (double)f0, (double)f1);
+            // newton (pyx:1349-1416), all f32
+            float lroot = (float)root;
+            {
+                int iteration = 0;
+                for (;;) {
+                    EvalOut e;
+                    eval_specific<C, true>(pr, xrow, lroot, lane, e);
+                    n_full++;
+                    const float d1 = d1_f(pr, lroot, e.yPy, e.yPPy, e.trP);
+                    const float d2 = d2_f(pr, lroot, e.yPy, e.yPPy, e.yPPPy, e.trP, e.trPP);
+                    const float ratio = __fdiv_rn(d1, d2);
+                    // np.sign(ratio)*np.sign(d1)*np.sign(d2) <= 0.0   (NaN compares False)
+                    const bool any_nan = (ratio != ratio) || (d1 != d1) || (d2 != d2);
+                    const float sr = (float)((ratio > 0) - (ratio < 0)), s1 = (float)((d1 > 0) - (d1 < 0)), s2 = (float)((d2 > 0) - (d2 < 0));
+                    if (!any_nan && sr * s1 * s2 <= 0.0f) break;
+                    const float lnew = __fsub_rn(lroot, ratio);
+                    const float r_eps = (float)(fabs((double)__fsub_rn(lnew, lroot)) / fabs((double)lroot));
+                    if (lnew < l0) break;
+                    if (lnew > l1) break;
+                    if (isnan(lnew) || isinf(lnew)) break;
+                    lroot = lnew;
+                    if ((double)r_eps < 1e-5 || iteration > 100) break;
+                    iteration++;
+                }
+            }
+            EvalOut e;
+            eval_specific<C, false>(pr, xrow, lroot, lane, e);   // pyx:186
+            n_fast++;
+            const float ldH = device_logdet_H(pr, lroot, lane, vals);
+            const float ll = logl_f(pr, e.yPy, ldH, e.ld);       // pyx:188
+            if (ll > best_l) { best_l = ll; best_lambda = lroot; best_e = e; }
+        }
+    }
+    // ---- beta, se, tau, F (pyx:1529-1537, lmm.py:471)
+    if (lane == 0) {
+        const float b = __fdiv_rn(best_e.Pyx_c, best_e.Pxx_c);
+        const float pxx = (PG_MINV > best_e.Pxx_c) ? PG_MINV : best_e.Pxx_c;
+        const float sb = (float)(__dsqrt_rn((double)best_e.yPy) / ((double)sqrtf(pxx) * __dsqrt_rn((double)(pr.nu))));
+        const float ta = __fdiv_rn((float)pr.nu, best_e.yPy);
+        const double t = (double)__fdiv_rn(b, sb);
+        pr.beta[g] = b; pr.se[g] = sb; pr.tau[g] = ta; pr.lam[g] = best_lambda; pr.F[g] = t * t;
+        if (pr.stats) { atomicAdd(&pr.stats[0], (unsigned long long)n_fast); atomicAdd(&pr.stats[1], (unsigned long long)n_full); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scipy.stats.f.sf(F, 1, dfd) (lmm.py:482): I_{w}(dfd/2, 1/2), w = dfd/(dfd+F) — same statements as
+// oracle orc_fdist_sf (continued fraction, modified Lentz).
+__device__ double betacf_dev(double a, double b, double x)
+{
+    const double FPMIN = 1e-300, EPS = 1e-16;
+    double qab = a + b, qap = a + 1.0, qam = a - 1.0, c = 1.0, dd = 1.0 - qab * x / qap, h;
+    if (fabs(dd) < FPMIN) dd = FPMIN;
+    dd = 1.0 / dd; h = dd;
+    for (int m = 1; m <= 2000; m++) {
+        int m2 = 2 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        dd = 1.0 + aa * dd; if (fabs(dd) < FPMIN) dd = FPMIN;
+        c = 1.0 + aa / c; if (fabs(c) < FPMIN) c = FPMIN;
+        dd = 1.0 / dd; h *= dd * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        dd = 1.0 + aa * dd; if (fabs(dd) < FPMIN) dd = FPMIN;
+        c = 1.0 + aa / c; if (fabs(c) < FPMIN) c = FPMIN;
+        dd = 1.0 / dd;
+        double del = dd * c;
+        h *= del;
+        if (fabs(del - 1.0) < EPS) break;
+    }
+    return h;
+}
+__global__ void fdist_sf_kernel(long long count, const double *F, double dfd, double *pval)
+{
+    long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count) return;
+    double f = F[g], r;
+    if (f != f) r = f;
+    else if (f <= 0.0) r = 1.0;
+    else if (isinf(f)) r = 0.0;
+    else {
+        double a = 0.5 * dfd, b = 0.5;
+        double x = dfd / (dfd + f), omx = 1.0 - x;
+        double lbeta = lgamma(a) + lgamma(b) - lgamma(a + b);
+        double lbt = a * log(x) + b * log(omx) - lbeta;
+        if (x < (a + 1.0) / (a + b + 2.0)) r = exp(lbt) * betacf_dev(a, b, x) / a;
+        else r = 1.0 - exp(lbt) * betacf_dev(b, a, omx) / b;
+    }
+    pval[g] = r;
+}
+
+// packed fixed rows: d, w_0..w_{c-1}, y, zero pad; rows [n, npad) zero
+__global__ void build_fixed_kernel(int n, int npad, int c, int rowf, const float *d, const float *Wr, const float *yr, float *fixed)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    float *row = fixed + (size_t)i * rowf;
+    for (int k = 0; k < rowf; k++) row[k] = 0.0f;
+    if (i < n) {
+        row[0] = d[i];
+        for (int j = 0; j < c; j++) row[1 + j] = Wr[(size_t)i * c + j];
+        row[c + 1] = yr[i];
+    }
+}
+
+// (n x p row-major) -> SNP-major (p x ldx), 32x32 LDS tile transpose, pad zeroed
+__global__ __launch_bounds__(256) void transpose_kernel(long long n, long long p, const float *X, float *Xr, long long ldx)
+{
+    __shared__ float tile[32][33];
+    const long long g0 = (long long)blockIdx.x * 32, i0 = (long long)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        long long i = i0 + r, g = g0 + tx;
+        tile[r][tx] = (i < n && g < p) ? X[(size_t)i * p + g] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        long long g = g0 + r, i = i0 + tx;
+        if (g < p && i < ldx) Xr[(size_t)g * ldx + i] = tile[tx][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+static size_t assoc_lds_bytes(int c, int n_vals)
+{
+    const int M = c + 2;
+    size_t per_wave = (size_t)NLAM * 2 * M * 8 + NLAM * sizeof(EvalOut) + 2 * NLAM * 4 + (size_t)n_vals * 4;
+    per_wave = (per_wave + 15) & ~(size_t)15;
+    return per_wave * WPB;
+}
+
+template <int C>
+static int launch_assoc(pg_ctx *ctx, AssocParams &pr)
+{
+    setup_tabs_kernel<C><<<NLAM, 64, (size_t)pr.n_vals * 4 + 16, ctx->stream>>>(pr);
+    PG_HIP(hipGetLastError());
+    const size_t lds = assoc_lds_bytes(C, pr.n_vals);
+    if (lds > 64 * 1024)
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&assoc_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long nblk = (pr.p + WPB - 1) / WPB;
+    assoc_kernel<C><<<dim3((unsigned)nblk), 64 * WPB, lds, ctx->stream>>>(pr);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" int pg_fdist_sf_dev(pg_ctx *ctx, int64_t count, const double *F, double dfd, double *pval)
+{
+    PG_REQUIRE(ctx && F && pval && count >= 0, "pg_fdist_sf_dev: bad arguments");
+    if (count == 0) return PG_OK;
+    PG_HIP(hipSetDevice(ctx->device));
+    fdist_sf_kernel<<<(unsigned)((count + 255) / 256), 256, 0, ctx->stream>>>(count, F, dfd, pval);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+extern "C" int pg_transpose_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *X, float *Xr, int64_t ldx)
+{
+    PG_REQUIRE(ctx && X && Xr && n > 0 && p > 0 && ldx >= n, "pg_transpose_dev: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((p + 31) / 32), (unsigned)((ldx + 31) / 32));
+    transpose_kernel<<<grid, 256, 0, ctx->stream>>>(n, p, X, Xr, ldx);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+extern "C" int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
+                            const float *Xr, int64_t ldx, int grid, float *beta, float *se, float *tau, float *lambda,
+                            double *F, double *pval, unsigned long long *stats_dev)
+{
+    PG_REQUIRE(ctx && d && Wr && yr && Xr && beta && se && tau && lambda && F, "pg_assoc_dev: NULL argument");
+    PG_REQUIRE(n >= 2 && n < (1LL << 30) && p >= 0 && ldx >= n, "pg_assoc_dev: bad shape n=%lld p=%lld ldx=%lld", (long long)n, (long long)p, (long long)ldx);
+    if (c < 1 || c > PG_MAX_COVARIATES) {
+        set_error("pg_assoc_dev: c=%d covariates not supported by this build (1..%d)", c, PG_MAX_COVARIATES);
+        return PG_ENOTSUP;
+    }
+    PG_REQUIRE(n - c - 1 > 0, "pg_assoc_dev: n - c - 1 must be positive");
+    if (p == 0) return PG_OK;
+    PG_HIP(hipSetDevice(ctx->device));
+    int rc = build_npsum_plan(ctx, n);
+    if (rc) return rc;
+
+    AssocParams pr{};
+    pr.n = (int)n; pr.npad = (int)((n + 63) / 64 * 64); pr.c = c; pr.niter = pr.npad / 64;
+    pr.nu = (int)(n - c - 1); pr.grid = grid ? 1 : 0; pr.rowf = ((c + 2 + 3) / 4) * 4;
+    pr.p = p; pr.ldx = ldx; pr.xr = Xr;
+    const int M = c + 2, NP = M * (M + 1) / 2;
+    rc = ensure(ctx, &ctx->fixed, &ctx->fixed_bytes, (size_t)pr.npad * pr.rowf * 4);
+    if (rc) return rc;
+    const size_t off_fixg = ((size_t)NLAM * pr.npad * 4 + 255) & ~(size_t)255;
+    const size_t off_t1 = off_fixg + (size_t)NLAM * 2 * NP * 8;
+    const size_t off_ldh = off_t1 + NLAM * 8;
+    rc = ensure(ctx, &ctx->tabs, &ctx->tabs_bytes, off_ldh + NLAM * 4 + 256);
+    if (rc) return rc;
+    if (!ctx->stats) PG_HIP(hipMalloc(&ctx->stats, 16));
+    pr.fixed = (const float *)ctx->fixed;
+    pr.htab = (float *)ctx->tabs;
+    pr.fixg = (double *)((char *)ctx->tabs + off_fixg);
+    pr.t1tab = (double *)((char *)ctx->tabs + off_t1);
+    pr.ldHtab = (float *)((char *)ctx->tabs + off_ldh);
+    for (int k = -5; k <= 5; k++) pr.lam11[k + 5] = (float)pow(10.0, (double)(float)k);  // pyx:122,157-158
+    {
+        const int ctot = c + 1;
+        float r = (float)((0.5 * (double)(n - ctot)) * std::log(0.5 * (double)(n - ctot) / M_PI));  // pyx:1821
+        r = (float)((double)r - (0.5 * (double)(n - ctot)));                                          // pyx:1822
+        pr.logl_c = r;
+    }
+    pr.leaf = ctx->plan.d_leaf; pr.node = ctx->plan.d_node; pr.level = ctx->plan.d_level; pr.chunk = ctx->plan.d_chunk;
+    pr.n_leaf = ctx->plan.n_leaf; pr.n_level = ctx->plan.n_level; pr.n_chunk = ctx->plan.n_chunk;
+    pr.n_vals = ctx->plan.n_leaf + ctx->plan.n_node;
+    pr.beta = beta; pr.se = se; pr.tau = tau; pr.lam = lambda; pr.F = F;
+    pr.stats = stats_dev;
+
+    build_fixed_kernel<<<(pr.npad + 255) / 256, 256, 0, ctx->stream>>>(pr.n, pr.npad, c, pr.rowf, d, Wr, yr, (float *)ctx->fixed);
+    PG_HIP(hipGetLastError());
+    switch (c) {
+#define PG_CASE(CC) case CC: rc = launch_assoc<CC>(ctx, pr); break;
+        PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6)
+        PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10) PG_CASE(11) PG_CASE(12)
+#undef PG_CASE
+        default: rc = PG_ENOTSUP;
+    }
+    if (rc) return rc;
+    if (pval) return pg_fdist_sf_dev(ctx, p, F, (double)(n - c - 1), pval);
+    return PG_OK;
+}

@@ -1,0 +1,53 @@
+"""Array-level wrappers over the C ABI (host NumPy in / out).  HIP path only."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def assoc(d, Wr, yr, Xr, grid=False, ctx=None, want_p=True, return_stats=False):
+    """calculate((eigenVals, Y, W, X_block, grid)) (lmm/lmm.py:461) on the GPU.
+    d (n,), Wr (n,c), yr (n,) or (n,1), Xr (n,p) in the REFERENCE layout, all in the eigenbasis."""
+    L = _lib.load()
+    own = ctx is None
+    ctx = ctx or _lib.Context(0)
+    try:
+        d, Wr, yr, Xr = _f32(d), _f32(Wr), _f32(np.asarray(yr).reshape(-1)), _f32(Xr)
+        n, c = Wr.shape
+        p = Xr.shape[1]
+        assert d.shape == (n,) and yr.shape == (n,) and Xr.shape[0] == n
+        beta, se, tau, lam = (np.empty(p, np.float32) for _ in range(4))
+        F, pv = np.empty(p, np.float64), np.empty(p, np.float64)
+        stats = np.zeros(2, np.uint64)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(L.pg_assoc(ctx.handle, n, c, p, vp(d), vp(Wr), vp(yr), vp(Xr), int(bool(grid)), vp(beta), vp(se),
+                              vp(tau), vp(lam), vp(F), vp(pv) if want_p else None, vp(stats)), "pg_assoc")
+        out = {"beta": beta, "se_beta": se, "tau": tau, "lambda": lam.astype(np.float64), "F_wald": F,
+               "p_wald": pv if want_p else None}
+        if return_stats:
+            out["n_evals"] = stats.astype(np.int64)
+        return out
+    finally:
+        if own:
+            ctx.close()
+
+
+def fdist_sf(F, dfd, ctx=None):
+    L = _lib.load()
+    own = ctx is None
+    ctx = ctx or _lib.Context(0)
+    try:
+        F = np.ascontiguousarray(F, np.float64).ravel()
+        dF = ctx.to_device(F)
+        dP = ctx.alloc(F.nbytes)
+        _lib.check(L.pg_fdist_sf_dev(ctx.handle, F.size, dF.ptr, float(dfd), dP.ptr), "pg_fdist_sf_dev")
+        ctx.sync()
+        return dP.download(F.shape, np.float64)
+    finally:
+        if own:
+            ctx.close()
