@@ -62,6 +62,8 @@ def lib():
         L.orc_wrapper_d1.argtypes = [C.c_float, f32p, f32p, f32p, C.c_long, C.c_int, C.c_int]
         L.orc_max_threads.restype = C.c_int
         L.orc_brentq.restype = C.c_double
+        L.orc_rotate.restype = None
+        L.orc_rotate.argtypes = [f32p, f32p, C.c_long, C.c_long, f32p, C.c_long]
         _lib = L
     return _lib
 
@@ -122,3 +124,14 @@ def calculate(d, y, W, X, grid=False, order=0, nthreads=1, snp_major=False, pval
     assert rc == 0
     return {"beta": beta, "se_beta": se, "tau": tau, "lambda": lam.astype(np.float64), "F_wald": F,
             "p_wald": pv if pvals else None, "n_evals": ne}
+
+
+def rotate(U, X, ldx=None):
+    """U.T @ X (lmm:243-246) as a k-ordered f32 fma chain; returns SNP-major (p, ldx)."""
+    L = lib()
+    U, X = _c(U), _c(X)
+    n, p = X.shape
+    ldx = ldx or (n + 63) // 64 * 64
+    out = np.empty((p, ldx), np.float32)
+    L.orc_rotate(U, X, n, p, out, ldx)
+    return out

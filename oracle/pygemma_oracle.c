@@ -735,3 +735,24 @@ int orc_max_threads(void)
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* lmm:243-246  X = U.T @ X  (float32 sgemm in the reference; its internal summation order is */
+/* OpenBLAS's and cannot be restated).  Restated as the k-ordered f32 fma chain                */
+/* Xr[g][k] = fmaf(X[i][g], U[i][k], .) for i = 0..n-1, which is also exactly what the fp32   */
+/* MFMA computes, so GPU == oracle bit-for-bit; vs the reference it is an f32-rounding-level   */
+/* (1e-6 relative to |X||U|) comparison.  Output SNP-major, row stride ldx, pad zeroed.        */
+/* ------------------------------------------------------------------------------------ */
+void orc_rotate(const float *U, const float *X, long n, long p, float *Xr, long ldx)
+{
+#pragma omp parallel for schedule(static)
+    for (long g = 0; g < p; g++) {
+        float *out = Xr + (size_t)g * ldx;
+        for (long k = 0; k < ldx; k++) out[k] = 0.0f;
+        for (long i = 0; i < n; i++) {
+            const float x = X[(size_t)i * p + g];
+            const float *u = U + (size_t)i * n;
+            for (long k = 0; k < n; k++) out[k] = fmaf(x, u[k], out[k]);
+        }
+    }
+}

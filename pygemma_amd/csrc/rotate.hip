@@ -1,7 +1,159 @@
-// rotate.hip — H2: X <- U' X on fp32 MFMA (placeholder until the GEMM lands in this round)
+// rotate.hip — H2: the eigen-rotation  X <- U' X  (lmm/lmm.py:243-246; OpenBLAS sgemm in the reference)
+// as an fp32-MFMA GEMM on gfx950, writing the SNP-major layout the association kernels read.
+//
+//   Xr[g][k] = sum_i X[i][g] * U[i][k]        M = p (SNPs g), N = n (eigen index k), K = n (samples i)
+//
+// Both operands are K-major in memory (X is (n,p) row-major, U is (n,n) row-major with eigenvector k in
+// column k), which is exactly the operand order v_mfma_f32_32x32x2_f32 wants from LDS tiles stored
+// [k][m] / [k][n]: lane l reads A[k = l>>5][m = l&31] and B[k = l>>5][n = l&31] — 32 consecutive floats
+// per half-wave, conflict-free ds_read_b32, and the global->LDS copies are straight 16-byte row segments.
+// fp32 in / fp32 accumulate: bit-for-bit a k-ordered fmaf chain, i.e. the reference's own precision class.
+//
+// Tile: 128(M) x 128(N) x 16(K) per 256-thread workgroup, 4 waves as 2x2, each wave 2x2 MFMA tiles of 32x32;
+// register-staged global loads for tile t+1 issued before the MFMAs of tile t, LDS double-buffered, one
+// barrier per K-tile.  blockIdx -> tile map is XCD-aware (blocks b and b+8 share an XCD, so the bijective
+// remap hands each XCD a contiguous run of tiles) and grouped 8 tile-rows deep so that the ~64 tiles an XCD
+// works on at once share their X and U panels in its 4 MiB L2.
 #include "common.hpp"
-extern "C" int pg_rotate_dev(pg_ctx *, int64_t, int64_t, const float *, const float *, float *, int64_t)
+
+namespace pg {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int RBM = 128, RBN = 128, RBK = 16, RGROUP = 8;
+
+struct RotParams {
+    long long n, p, ldx;
+    const float *U, *X;
+    float *Xr;
+    int tiles_m, tiles_n;
+};
+
+template <int VEC>
+__device__ __forceinline__ float4 load4(const float *base, long long row, long long ld, long long col, long long nrow, long long ncol)
 {
-    pg::set_error("pg_rotate_dev: not built yet");
-    return PG_ENOTSUP;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrow) {
+        const float *p = base + row * ld + col;
+        if (VEC == 4 && col + 3 < ncol) {
+            v = *reinterpret_cast<const float4 *>(p);
+        } else {
+            if (col < ncol) v.x = p[0];
+            if (col + 1 < ncol) v.y = p[1];
+            if (col + 2 < ncol) v.z = p[2];
+            if (col + 3 < ncol) v.w = p[3];
+        }
+    }
+    return v;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256, 2) void rotate_kernel(RotParams rp)
+{
+    __shared__ float As[2][RBK][RBM];
+    __shared__ float Bs[2][RBK][RBN];
+    // ---- XCD-aware, grouped tile order
+    const int T = rp.tiles_m * rp.tiles_n;
+    const int b = blockIdx.x;
+    const int q = T / 8, r = T % 8, xcd = b % 8;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    const int per_group = RGROUP * rp.tiles_n;
+    const int grp = lid / per_group;
+    const int first_m = grp * RGROUP;
+    const int gsz = (rp.tiles_m - first_m) < RGROUP ? (rp.tiles_m - first_m) : RGROUP;
+    const int tm = first_m + (lid % per_group) % gsz;
+    const int tn = (lid % per_group) / gsz;
+    const long long m0 = (long long)tm * RBM, n0 = (long long)tn * RBN;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = tid >> 5, lcol = (tid & 31) * 4;   // global->LDS: 8 rows x 32 float4 per pass
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    const int KT = (int)((rp.n + RBK - 1) / RBK);
+    float4 ra[2], rb[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        ra[h] = load4<VEC>(rp.X, h * 8 + lrow, rp.p, m0 + lcol, rp.n, rp.p);
+        rb[h] = load4<VEC>(rp.U, h * 8 + lrow, rp.n, n0 + lcol, rp.n, rp.n);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        *reinterpret_cast<float4 *>(&As[0][h * 8 + lrow][lcol]) = ra[h];
+        *reinterpret_cast<float4 *>(&Bs[0][h * 8 + lrow][lcol]) = rb[h];
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) {
+            const long long k0 = (long long)(kt + 1) * RBK;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                ra[h] = load4<VEC>(rp.X, k0 + h * 8 + lrow, rp.p, m0 + lcol, rp.n, rp.p);
+                rb[h] = load4<VEC>(rp.U, k0 + h * 8 + lrow, rp.n, n0 + lcol, rp.n, rp.n);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < RBK; kk += 2) {
+            const int kr = kk + (lane >> 5);
+            const float a0 = As[buf][kr][wm * 64 + (lane & 31)];
+            const float a1 = As[buf][kr][wm * 64 + 32 + (lane & 31)];
+            const float b0 = Bs[buf][kr][wn * 64 + (lane & 31)];
+            const float b1 = Bs[buf][kr][wn * 64 + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                *reinterpret_cast<float4 *>(&As[buf ^ 1][h * 8 + lrow][lcol]) = ra[h];
+                *reinterpret_cast<float4 *>(&Bs[buf ^ 1][h * 8 + lrow][lcol]) = rb[h];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- C/D map of the 32x32 f32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const long long col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const long long row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < rp.p && col < rp.ldx) rp.Xr[row * rp.ldx + col] = acc[i][j][e];
+            }
+        }
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" int pg_rotate_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, const float *X, float *Xr, int64_t ldx)
+{
+    PG_REQUIRE(ctx && U && X && Xr, "pg_rotate_dev: NULL argument");
+    PG_REQUIRE(n > 0 && p > 0 && ldx >= n && ldx <= (n + 127) / 128 * 128, "pg_rotate_dev: bad shape n=%lld p=%lld ldx=%lld (need n <= ldx <= roundup(n,128))",
+               (long long)n, (long long)p, (long long)ldx);
+    PG_HIP(hipSetDevice(ctx->device));
+    RotParams rp{};
+    rp.n = n; rp.p = p; rp.ldx = ldx; rp.U = U; rp.X = X; rp.Xr = Xr;
+    rp.tiles_m = (int)((p + RBM - 1) / RBM);
+    rp.tiles_n = (int)((n + RBN - 1) / RBN);
+    const long long T = (long long)rp.tiles_m * rp.tiles_n;
+    PG_REQUIRE(T < (1LL << 31), "pg_rotate_dev: too many tiles; rotate in SNP batches");
+    const bool vec = (n % 4 == 0) && (p % 4 == 0) && (((uintptr_t)U | (uintptr_t)X) % 16 == 0);
+    if (vec) rotate_kernel<4><<<dim3((unsigned)T), 256, 0, ctx->stream>>>(rp);
+    else rotate_kernel<1><<<dim3((unsigned)T), 256, 0, ctx->stream>>>(rp);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
 }

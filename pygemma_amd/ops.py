@@ -51,3 +51,26 @@ def fdist_sf(F, dfd, ctx=None):
     finally:
         if own:
             ctx.close()
+
+
+def rotate(U, X, ctx=None, ldx=None):
+    """X <- U' X (lmm/lmm.py:243-246) on the GPU; U (n,n) eigenvectors in columns, X (n,p).
+    Returns the SNP-major rotated block (p, ldx) float32."""
+    L = _lib.load()
+    own = ctx is None
+    ctx = ctx or _lib.Context(0)
+    try:
+        U, X = _f32(U), _f32(X)
+        n, p = X.shape
+        ldx = ldx or (n + 63) // 64 * 64
+        dU, dX = ctx.to_device(U), ctx.to_device(X)
+        dXr = ctx.alloc(p * ldx * 4)
+        _lib.check(L.pg_rotate_dev(ctx.handle, n, p, dU.ptr, dX.ptr, dXr.ptr, ldx), "pg_rotate_dev")
+        ctx.sync()
+        out = dXr.download((p, ldx), np.float32)
+        for b in (dU, dX, dXr):
+            b.free()
+        return out
+    finally:
+        if own:
+            ctx.close()
