@@ -1,0 +1,130 @@
+// dgemm.hpp — fp64 MFMA GEMM (v_mfma_f64_16x16x4_f64) used by the eigensolver: the syr2k trailing update
+// of the Householder tridiagonalisation, the divide-and-conquer merges and the back-transformation.
+//
+//   C (MxN, row-major, ldc) = alpha * op(A) * B + beta * C
+//   TA = false : A is M x K row-major (lda)            TA = true : A is stored K x M row-major (lda)
+//   B is K x N row-major (ldb)
+//
+// 128x128x8 tile per 256-thread workgroup (4 waves as 2x2, each 4x4 MFMA tiles of 16x16), LDS tiles kept
+// K-major ([k][m], [k][n]) so a wave's operand read is 16 consecutive doubles per k-row; rows padded by 16
+// doubles so the four k-rows a ds_read_b64 touches fall on disjoint bank halves.  f64 MFMA lane maps:
+// A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], C/D col = l&15, row = (l>>4) + 4*reg.
+#pragma once
+#include "common.hpp"
+
+namespace pg {
+
+typedef double doublex4 __attribute__((ext_vector_type(4)));
+
+constexpr int DBM = 128, DBN = 128, DBK = 8, DPAD = 16;
+
+struct DgemmParams {
+    long long M, N, K, lda, ldb, ldc;
+    const double *A, *B;
+    double *C;
+    double alpha, beta;
+};
+
+template <bool TA>
+__global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
+{
+    __shared__ double As[2][DBK][DBM + DPAD];
+    __shared__ double Bs[2][DBK][DBN + DPAD];
+    const int tiles_n = (int)((gp.N + DBN - 1) / DBN);
+    const long long m0 = (long long)(blockIdx.x / tiles_n) * DBM, n0 = (long long)(blockIdx.x % tiles_n) * DBN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    doublex4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[i][j][e] = 0.0;
+
+    double ra[4], rb[4];
+    auto gload = [&](long long k0) {
+        // B tile: 8 rows (k) x 128 cols: thread -> row tid/32, 4 consecutive cols
+        {
+            const long long kr = k0 + (tid >> 5), col = n0 + (tid & 31) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) rb[q] = (kr < gp.K && col + q < gp.N) ? gp.B[kr * gp.ldb + col + q] : 0.0;
+        }
+        if (TA) {
+            const long long kr = k0 + (tid >> 5), col = m0 + (tid & 31) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) ra[q] = (kr < gp.K && col + q < gp.M) ? gp.A[kr * gp.lda + col + q] : 0.0;
+        } else {
+            // A tile: 128 rows (m) x 8 (k): thread -> row tid/2, 4 consecutive k
+            const long long row = m0 + (tid >> 1), kc = k0 + (tid & 1) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) ra[q] = (row < gp.M && kc + q < gp.K) ? gp.A[row * gp.lda + kc + q] : 0.0;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) Bs[buf][tid >> 5][(tid & 31) * 4 + q] = rb[q];
+        if (TA) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) As[buf][tid >> 5][(tid & 31) * 4 + q] = ra[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) As[buf][(tid & 1) * 4 + q][tid >> 1] = ra[q];
+        }
+    };
+
+    const int KT = (int)((gp.K + DBK - 1) / DBK);
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) gload((long long)(kt + 1) * DBK);
+#pragma unroll
+        for (int kk = 0; kk < DBK; kk += 4) {
+            const int kr = kk + (lane >> 4);
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = As[buf][kr][wm * 64 + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = Bs[buf][kr][wn * 64 + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const long long col = n0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const long long row = m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * e;
+                if (row < gp.M && col < gp.N) {
+                    double *c = gp.C + row * gp.ldc + col;
+                    double v = gp.alpha * acc[i][j][e];
+                    if (gp.beta != 0.0) v += gp.beta * (*c);
+                    *c = v;
+                }
+            }
+        }
+}
+
+inline int dgemm(pg_ctx *ctx, bool transA, long long M, long long N, long long K, double alpha, const double *A, long long lda,
+                 const double *B, long long ldb, double beta, double *C, long long ldc)
+{
+    if (M <= 0 || N <= 0) return PG_OK;
+    DgemmParams gp{M, N, K, lda, ldb, ldc, A, B, C, alpha, beta};
+    const long long tiles = ((M + DBM - 1) / DBM) * ((N + DBN - 1) / DBN);
+    if (transA) dgemm_kernel<true><<<dim3((unsigned)tiles), 256, 0, ctx->stream>>>(gp);
+    else dgemm_kernel<false><<<dim3((unsigned)tiles), 256, 0, ctx->stream>>>(gp);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+}  // namespace pg

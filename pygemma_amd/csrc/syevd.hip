@@ -1,7 +1,760 @@
-// syevd.hip — H1: eigendecomposition of K in fp64 (placeholder until it lands in this round)
+// syevd.hip — H1: eigendecomposition of the relatedness matrix K (lmm/lmm.py:151-162 / :196-207; the
+// reference calls scipy.linalg.eigh = LAPACK ssyevr in float32).  Built from scratch for gfx950, in fp64:
+//
+//   1. blocked Householder tridiagonalisation  K = Q T Q'   (panel of NB reflectors: one HBM-bound symv per
+//      column + small panel GEMVs, then a rank-2NB trailing update on fp64 MFMA)
+//   2. divide and conquer on T (rank-one merges: deflation on the host — O(n) sequential — secular
+//      equation, Loewner-corrected vectors and the eigenvector GEMMs on the device)
+//   3. back-transformation  U = Q Z  with blocked compact-WY reflectors (fp64 MFMA GEMMs)
+//
+// Delivered like the reference: ascending eigenvalues clamped at 0 (lmm.py:157) in float32, U with
+// eigenvector j in column j in float32 — plus the fp64 pair for the invariant checks.  Parity is judged by
+// invariants (residual, orthogonality, agreement with host LAPACK in fp64), not by agreement with the
+// reference's float32 LAPACK (SURVEY 8c Tier B).
 #include "common.hpp"
-extern "C" int pg_syevd_dev(pg_ctx *, int64_t, const float *, float *, float *, double *, double *)
+#include "dgemm.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace pg {
+
+constexpr int NB = 64;  // reflectors per panel
+static int alloc_d(double **p, size_t count);
+
+// ---------------------------------------------------------------------------------------------
+__global__ void sym_from_lower_kernel(long long n, const float *K, double *A)
 {
-    pg::set_error("pg_syevd_dev: not built yet");
-    return PG_ENOTSUP;
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    long long i = idx / n, j = idx % n;
+    A[idx] = (double)(i >= j ? K[i * n + j] : K[j * n + i]);
+}
+
+__device__ __forceinline__ double block_sum(double v, double *sh)
+{
+    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < nw; w++) t += sh[w];
+    return t;
+}
+
+// column i of A with the pending panel updates applied:  a = A[:,i] - V W[i,:]' - W V[i,:]'
+// P = [V ; W ; V] stacked (3*NB x n), panel column c of V at P[c*n + r], of W at P[(NB+c)*n + r]
+__global__ void panel_col_kernel(int n, int i, int ci, const double *A, const double *P, double *acol)
+{
+    int r = i + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double acc = A[(size_t)r * n + i];
+    const double *V = P, *W = P + (size_t)NB * n;
+    for (int c = 0; c < ci; c++) acc -= V[(size_t)c * n + r] * W[(size_t)c * n + i] + W[(size_t)c * n + r] * V[(size_t)c * n + i];
+    acol[r] = acc;
+}
+
+// Householder reflector for acol[i+1:], one workgroup.  v (with v[i+1] = 1, zeros above) goes to panel column
+// ci of V (both copies), to column i of Vall (row-major n x n) and to vcur; d[i], e[i], tau[i] recorded.
+__global__ __launch_bounds__(1024) void larfg_kernel(int n, int i, int ci, const double *acol, double *P, double *Vall,
+                                                      double *vcur, double *dvec, double *evec, double *tauvec)
+{
+    __shared__ double sh[16];
+    const int tid = threadIdx.x;
+    double ss = 0.0;
+    for (int r = i + 2 + tid; r < n; r += blockDim.x) ss += acol[r] * acol[r];
+    const double xnorm2 = block_sum(ss, sh);
+    const double alpha = acol[i + 1];
+    double beta, tau, scal;
+    if (xnorm2 == 0.0) { beta = alpha; tau = 0.0; scal = 0.0; }
+    else {
+        beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+        tau = (beta - alpha) / beta;
+        scal = 1.0 / (alpha - beta);
+    }
+    double *V1 = P + (size_t)ci * n, *V2 = P + (size_t)(2 * NB + ci) * n;
+    for (int r = tid; r < n; r += blockDim.x) {
+        double v = 0.0;
+        if (r == i + 1) v = 1.0;
+        else if (r > i + 1) v = acol[r] * scal;
+        V1[r] = v; V2[r] = v; vcur[r] = v;
+        Vall[(size_t)r * n + i] = v;
+    }
+    if (tid == 0) { dvec[i] = acol[i]; evec[i] = beta; tauvec[i] = tau; }
+}
+
+// y[r] = sum_{c>i} A[r][c] v[c]  for r > i: one wavefront per row, lanes across columns
+__global__ __launch_bounds__(256) void symv_kernel(int n, int i, const double *A, const double *v, double *y)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = i + 1 + blockIdx.x * 4 + wave;
+    if (r >= n) return;
+    const double *row = A + (size_t)r * n;
+    double acc = 0.0;
+    for (int c = i + 1 + lane; c < n; c += 64) acc = fma(row[c], v[c], acc);
+    for (int s = 1; s < 64; s <<= 1) acc += __shfl_xor(acc, s, 64);
+    if (lane == 0) y[r] = acc;
+}
+
+// t[b] = W[b,:] . v (b < ci) ; t[ci + b] = V[b,:] . v
+__global__ __launch_bounds__(256) void panel_dots_kernel(int n, int i, int ci, const double *P, const double *v, double *t)
+{
+    __shared__ double sh[4];
+    const int b = blockIdx.x;
+    const double *src = (b < ci) ? P + (size_t)(NB + b) * n : P + (size_t)(b - ci) * n;
+    double acc = 0.0;
+    for (int r = i + 1 + threadIdx.x; r < n; r += blockDim.x) acc = fma(src[r], v[r], acc);
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) t[b] = acc;
+}
+
+// w = tau * (y - V t1 - W t2) ; partial[block] = sum w.v
+__global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, const double *P, const double *v, const double *y,
+                                                       const double *t, const double *tauvec, double *wtmp, double *partial)
+{
+    __shared__ double sh[4];
+    const int r = i + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    double wv = 0.0;
+    if (r < n) {
+        double acc = y[r];
+        const double *V = P, *W = P + (size_t)NB * n;
+        for (int c = 0; c < ci; c++) acc -= V[(size_t)c * n + r] * t[c] + W[(size_t)c * n + r] * t[ci + c];
+        acc *= tauvec[i];
+        wtmp[r] = acc;
+        wv = acc * v[r];
+    }
+    wv = block_sum(wv, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = wv;
+}
+
+// W[ci,:] = w - (tau/2)(w.v) v
+__global__ __launch_bounds__(256) void w_final_kernel(int n, int i, int ci, int nblk, double *P, const double *v, const double *wtmp,
+                                                      const double *tauvec, const double *partial)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double dot = 0.0;
+    for (int b = 0; b < nblk; b++) dot += partial[b];
+    const double alpha = -0.5 * tauvec[i] * dot;
+    P[(size_t)(NB + ci) * n + r] = (r > i) ? wtmp[r] + alpha * v[r] : 0.0;
+}
+
+struct SytrdWork {
+    double *A = nullptr, *P = nullptr, *Vall = nullptr, *acol = nullptr, *vcur = nullptr, *y = nullptr, *t = nullptr,
+           *wtmp = nullptr, *partial = nullptr, *d = nullptr, *e = nullptr, *tau = nullptr;
+};
+
+// Householder tridiagonalisation of the symmetric fp64 matrix A (n x n, full storage, destroyed).
+// Outputs (device): d[n], e[n-1], tau[n-1], Vall (n x n row-major, column i = v_i).
+static int sytrd_device(pg_ctx *ctx, int n, SytrdWork &w)
+{
+    hipStream_t s = ctx->stream;
+    for (int i0 = 0; i0 < n - 1; i0 += NB) {
+        const int nbc = std::min(NB, n - 1 - i0);
+        PG_HIP(hipMemsetAsync(w.P, 0, (size_t)3 * NB * n * sizeof(double), s));
+        for (int ci = 0; ci < nbc; ci++) {
+            const int i = i0 + ci;
+            const int rows = n - i;
+            panel_col_kernel<<<(rows + 255) / 256, 256, 0, s>>>(n, i, ci, w.A, w.P, w.acol);
+            larfg_kernel<<<1, 1024, 0, s>>>(n, i, ci, w.acol, w.P, w.Vall, w.vcur, w.d, w.e, w.tau);
+            const int nt = n - i - 1;
+            symv_kernel<<<(nt + 3) / 4, 256, 0, s>>>(n, i, w.A, w.vcur, w.y);
+            if (ci > 0) panel_dots_kernel<<<2 * ci, 256, 0, s>>>(n, i, ci, w.P, w.vcur, w.t);
+            const int nblk = (nt + 255) / 256;
+            w_update_kernel<<<nblk, 256, 0, s>>>(n, i, ci, w.P, w.vcur, w.y, w.t, w.tau, w.wtmp, w.partial);
+            w_final_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, i, ci, nblk, w.P, w.vcur, w.wtmp, w.tau, w.partial);
+        }
+        PG_HIP(hipGetLastError());
+        const int off = i0 + nbc;
+        const long long nt = n - off;
+        if (nt > 0) {
+            // A22 -= V W' + W V'   as one TN GEMM with K = 2*NB:  [V;W]' [W;V]
+            int rc = dgemm(ctx, true, nt, nt, 2 * NB, -1.0, w.P + off, n, w.P + (size_t)NB * n + off, n, 1.0,
+                           w.A + (size_t)off * n + off, n);
+            if (rc) return rc;
+        }
+    }
+    // last diagonal entry
+    panel_col_kernel<<<1, 256, 0, s>>>(n, n - 1, 0, w.A, w.P, w.acol);
+    PG_HIP(hipMemcpyAsync(w.d + (n - 1), w.acol + (n - 1), sizeof(double), hipMemcpyDeviceToDevice, s));
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+
+// =============================================================================================
+// Divide and conquer for the symmetric tridiagonal eigenproblem  T = Z diag(lam) Z'.
+// Cuppen's rank-one splitting with Gu/Eisenstat's stable eigenvector formula (the structure of LAPACK
+// dstedc/dlaed0-4, re-derived for a host + GPU split): small leaves by implicit QL on the host; per merge
+// the O(n) sort + deflation scan on the host, everything O(n^2)/O(n^3) on the device — one thread per
+// secular root, one wavefront per Loewner product, fp64 MFMA GEMM for the eigenvector update.
+// =============================================================================================
+constexpr int DC_LEAF = 32;
+
+// implicit-shift QL for a small symmetric tridiagonal (EISPACK tql2 lineage); Z (m x m row-major, ldz) in/out
+static int host_tql2(int m, double *d, double *e, double *Z, int ldz)
+{
+    const double eps = 2.220446049250313e-16;
+    for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Z[(size_t)i * ldz + j] = (i == j) ? 1.0 : 0.0;
+    if (m == 1) return 0;
+    e[m - 1] = 0.0;
+    for (int l = 0; l < m; l++) {
+        int iter = 0, mm;
+        do {
+            for (mm = l; mm < m - 1; mm++) {
+                double dd = fabs(d[mm]) + fabs(d[mm + 1]);
+                if (fabs(e[mm]) <= eps * dd) break;
+            }
+            if (mm != l) {
+                if (iter++ == 300) return -1;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = hypot(g, 1.0);
+                g = d[mm] - d[l] + e[l] / (g + copysign(r, g));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = mm - 1; i >= l; i--) {
+                    double f = s * e[i], b = c * e[i];
+                    r = hypot(f, g);
+                    e[i + 1] = r;
+                    if (r == 0.0) { d[i + 1] -= p; e[mm] = 0.0; break; }
+                    s = f / r; c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    p = s * r;
+                    d[i + 1] = g + p;
+                    g = c * r - b;
+                    for (int k = 0; k < m; k++) {
+                        double *zk = Z + (size_t)k * ldz;
+                        f = zk[i + 1];
+                        zk[i + 1] = s * zk[i] + c * f;
+                        zk[i] = c * zk[i] - s * f;
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p; e[l] = g; e[mm] = 0.0;
+            }
+        } while (mm != l);
+    }
+    return 0;
+}
+
+__global__ void scatter_leaves_kernel(int n, int ldS, const double *S, const int *leaf_start, const int *leaf_size, const int *leaf_of_row, double *Q)
+{
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * ldS) return;
+    int r = (int)(idx / ldS), j = (int)(idx % ldS);
+    int lf = leaf_of_row[r];
+    if (j < leaf_size[lf]) Q[(size_t)r * n + leaf_start[lf] + j] = S[idx];
+}
+
+__global__ void gather_z_kernel(int n, const double *Q, const int *zrow, double *z)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int r = zrow[i];
+    z[i] = (r >= 0) ? Q[(size_t)r * n + i] : 0.0;
+}
+
+struct Rot { int a, b; double c, s; };
+
+// apply the deflation rotations (in order) to columns of Q, rows [r0, r0+nrow): one thread per row
+__global__ void givens_kernel(int n, int r0, int nrow, double *Q, const Rot *rots, int nrot)
+{
+    int r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= r0 + nrow) return;
+    double *row = Q + (size_t)r * n;
+    for (int t = 0; t < nrot; t++) {
+        Rot g = rots[t];
+        double x = row[g.a], y = row[g.b];
+        row[g.a] = g.c * x + g.s * y;
+        row[g.b] = g.c * y - g.s * x;
+    }
+}
+
+// Tp[r][jj] = Qin[r0+r][col[jj]] (jj < k: non-deflated, in secular order);  deflated columns go straight to Qout
+__global__ void permute_cols_kernel(int n, int r0, int nm, int k, const double *Qin, const int *col, double *Tp, double *Qout)
+{
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)nm * nm) return;
+    int r = (int)(idx / nm), jj = (int)(idx % nm);
+    double v = Qin[(size_t)(r0 + r) * n + col[jj]];
+    if (jj < k) Tp[(size_t)r * k + jj] = v;
+    else Qout[(size_t)(r0 + r) * n + r0 + jj] = v;
+}
+
+// One thread per root of  f(lam) = 1 + rho * sum_i w_i^2 / (dl_i - lam)  (rho > 0, dl strictly increasing).
+// Root j lies in (dl_j, dl_{j+1}) (last: (dl_{k-1}, dl_{k-1} + rho*|w|^2]).  The origin is moved to the
+// nearer pole and the iteration runs on the offset tau, so that every difference dl_i - lam_j is obtained
+// as (dl_i - dl_origin) - tau without cancellation.  Rational ("middle way") steps, bracket-safeguarded.
+__global__ __launch_bounds__(256) void secular_kernel(int k, const double *dl, const double *w, double rho, double *Dm, double *lam_out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    const double eps = 1.1102230246251565e-16;
+    int org;
+    double lo, hi, tau;
+    const bool last = (j == k - 1);
+    if (last) {
+        double sw = 0.0;
+        for (int i = 0; i < k; i++) sw += w[i] * w[i];
+        org = k - 1; lo = 0.0; hi = rho * sw; tau = 0.5 * hi;
+        if (k == 1) tau = hi;
+    } else {
+        const double gap = dl[j + 1] - dl[j], half = 0.5 * gap;
+        double fm = 1.0;   // f at the midpoint, deltas taken from dl[j]
+        for (int i = 0; i < k; i++) fm += rho * w[i] * w[i] / ((dl[i] - dl[j]) - half);
+        if (fm >= 0.0) { org = j; lo = 0.0; hi = half; tau = 0.5 * half; }
+        else { org = j + 1; lo = -half; hi = 0.0; tau = -0.5 * half; }
+        if (fm == 0.0) { lo = hi = tau = half; }
+    }
+    const double dorg = dl[org];
+    const int jp = last ? k - 1 : j;   // psi: i <= jp, phi: i > jp
+    for (int it = 0; it < 400 && lo != hi; it++) {
+        double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0, sabs = 0.0;
+        for (int i = 0; i < k; i++) {
+            const double del = (dl[i] - dorg) - tau;
+            const double t = rho * w[i] * w[i] / del;
+            if (i <= jp) { psi += t; dpsi += t / del; } else { phi += t; dphi += t / del; }
+            sabs += fabs(t);
+        }
+        const double f = 1.0 + psi + phi;
+        if (f == 0.0) break;
+        if (f < 0.0) lo = tau; else hi = tau;   // f is increasing on the interval
+        if (fabs(f) <= 8.0 * eps * (1.0 + sabs + fabs(tau) * (dpsi + dphi))) break;
+        if (hi - lo <= 2.0 * eps * fmax(fabs(lo), fabs(hi))) break;
+        double tnew;
+        if (last) {
+            // one pole at dl_{k-1} (delta 0) + constant:  c + S/(0 - t) = 0
+            const double A = -tau, S = (dpsi + dphi) * A * A, c = f - (dpsi + dphi) * A;
+            tnew = (c > 0.0) ? S / c : 2.0 * tau;
+        } else {
+            const double A = (dl[j] - dorg) - tau, B = (dl[j + 1] - dorg) - tau;
+            const double S = dpsi * A * A, R = dphi * B * B, c = f - dpsi * A - dphi * B;
+            const double qa = c, qb = c * (A + B) + S + R, qc = A * B * f;
+            double eta;
+            if (qa == 0.0) eta = qc / qb;
+            else {
+                const double disc = sqrt(fabs(qb * qb - 4.0 * qa * qc));
+                eta = (qb <= 0.0) ? (qb - disc) / (2.0 * qa) : 2.0 * qc / (qb + disc);
+            }
+            if (f * eta >= 0.0) eta = -f / (dpsi + dphi);
+            tnew = tau + eta;
+        }
+        if (!(tnew > lo && tnew < hi) || it > 40) {
+            // bisection; geometric when the bracket spans orders of magnitude on one side of 0
+            if (lo > 0.0 && hi > 4.0 * lo) tnew = sqrt(lo * hi);
+            else if (hi < 0.0 && lo < 4.0 * hi) tnew = -sqrt(lo * hi);
+            else if (lo == 0.0 && hi > 0.0) tnew = (it > 60) ? hi * 1e-3 : 0.5 * hi;
+            else if (hi == 0.0 && lo < 0.0) tnew = (it > 60) ? lo * 1e-3 : 0.5 * lo;
+            else tnew = 0.5 * (lo + hi);
+        }
+        if (tnew == tau) break;
+        tau = tnew;
+    }
+    for (int i = 0; i < k; i++) Dm[(size_t)i * k + j] = (dl[i] - dorg) - tau;
+    lam_out[j] = dorg + tau;
+}
+
+// zhat_i = sign(w_i) sqrt| Dm[i][i] * prod_{j != i} Dm[i][j] / (dl_i - dl_j) |   (one wavefront per i)
+__global__ __launch_bounds__(256) void zhat_kernel(int k, const double *dl, const double *w, const double *Dm, double *zh)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= k) return;
+    const double *row = Dm + (size_t)i * k;
+    const double di = dl[i];
+    double prod = 1.0;
+    for (int j = lane; j < k; j += 64) prod *= (j == i) ? row[j] : row[j] / (di - dl[j]);
+    for (int s = 1; s < 64; s <<= 1) prod *= __shfl_xor(prod, s, 64);
+    if (lane == 0) zh[i] = copysign(sqrt(fabs(prod)), w[i]);
+}
+
+// U[:, j] = (zh_i / Dm[i][j])_i, normalised; in place over Dm (one thread per column: coalesced across j)
+__global__ __launch_bounds__(256) void uvec_kernel(int k, const double *zh, double *Dm)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    double ss = 0.0;
+    for (int i = 0; i < k; i++) { double v = zh[i] / Dm[(size_t)i * k + j]; ss += v * v; }
+    const double inv = 1.0 / sqrt(ss);
+    for (int i = 0; i < k; i++) { double v = zh[i] / Dm[(size_t)i * k + j]; Dm[(size_t)i * k + j] = v * inv; }
+}
+
+__global__ void copy_block_kernel(int n, int r0, int nm, const double *Qin, double *Qout)
+{
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)nm * nm) return;
+    int r = r0 + (int)(idx / nm), c = r0 + (int)(idx % nm);
+    Qout[(size_t)r * n + c] = Qin[(size_t)r * n + c];
+}
+
+__global__ void permute_final_kernel(int n, const double *Qin, const int *col, double *Qout)
+{
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * n) return;
+    int r = (int)(idx / n), j = (int)(idx % n);
+    Qout[idx] = Qin[(size_t)r * n + col[j]];
+}
+
+struct MergePlan {
+    int s, n1, nm, k;
+    double rho;
+    std::vector<double> dl, w, ddefl;   // non-deflated poles/weights; values of the deflated columns
+    std::vector<int> col;               // global source column for each output slot (k non-deflated, then deflated)
+    std::vector<Rot> rots;
+};
+
+// host: sort + deflation (the dlaed2 scan).  d, z: block-local arrays of length nm (z2 already sign-adjusted).
+static void plan_merge(MergePlan &mp, const double *d_in, const double *z_in, double beta)
+{
+    const int nm = mp.nm;
+    const double eps = 1.1102230246251565e-16;
+    std::vector<double> d(d_in, d_in + nm), z(nm);
+    const double sgn = (beta < 0.0) ? -1.0 : 1.0;
+    for (int i = 0; i < nm; i++) z[i] = z_in[i] * ((i >= mp.n1) ? sgn : 1.0) * 0.7071067811865475244;
+    mp.rho = 2.0 * fabs(beta);
+    std::vector<int> idx(nm);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return d[a] < d[b]; });
+    double dmax = 0.0, zmax = 0.0;
+    for (int i = 0; i < nm; i++) { dmax = std::max(dmax, fabs(d[i])); zmax = std::max(zmax, fabs(z[i])); }
+    const double tol = 8.0 * eps * std::max(dmax, zmax);
+    mp.k = 0; mp.dl.clear(); mp.w.clear(); mp.ddefl.clear(); mp.col.clear(); mp.rots.clear();
+    std::vector<int> defl_cols;
+    if (mp.rho * zmax <= tol) {
+        for (int jj = 0; jj < nm; jj++) { defl_cols.push_back(idx[jj]); mp.ddefl.push_back(d[idx[jj]]); }
+    } else {
+        int pj = -1;
+        std::vector<int> nd;
+        for (int jj = 0; jj < nm; jj++) {
+            const int nj = idx[jj];
+            if (mp.rho * fabs(z[nj]) <= tol) { defl_cols.push_back(nj); mp.ddefl.push_back(d[nj]); continue; }
+            if (pj < 0) { pj = nj; continue; }
+            double s_ = z[pj], c_ = z[nj];
+            const double tau = hypot(c_, s_), t = d[nj] - d[pj];
+            c_ /= tau; s_ = -s_ / tau;
+            if (fabs(t * c_ * s_) <= tol) {
+                z[nj] = tau; z[pj] = 0.0;
+                mp.rots.push_back({mp.s + pj, mp.s + nj, c_, s_});
+                const double tt = d[pj] * c_ * c_ + d[nj] * s_ * s_;
+                d[nj] = d[pj] * s_ * s_ + d[nj] * c_ * c_;
+                d[pj] = tt;
+                defl_cols.push_back(pj); mp.ddefl.push_back(d[pj]);
+                pj = nj;
+            } else { nd.push_back(pj); pj = nj; }
+        }
+        if (pj >= 0) nd.push_back(pj);
+        mp.k = (int)nd.size();
+        for (int q : nd) { mp.dl.push_back(d[q]); mp.w.push_back(z[q]); mp.col.push_back(mp.s + q); }
+    }
+    for (int q : defl_cols) mp.col.push_back(mp.s + q);
+}
+
+struct StedcWork {
+    double *Qa = nullptr, *Qb = nullptr, *Tp = nullptr, *Um = nullptr, *z = nullptr, *dnew = nullptr, *dl = nullptr, *w = nullptr, *zh = nullptr, *S = nullptr;
+    int *ibuf = nullptr;   // zrow | col | leaf tables
+    Rot *rots = nullptr;
+};
+
+// T = tridiag(d, e) (host arrays, length n / n-1) -> ascending eigenvalues (host) and Z (device, n x n row-major,
+// eigenvector j in column j).  *Zout points into the work buffers.
+static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_in, std::vector<double> &evals, StedcWork &wk, double **Zout)
+{
+    hipStream_t st = ctx->stream;
+    std::vector<double> d(d_in, d_in + n), e(e_in, e_in + (n > 1 ? n - 1 : 0));
+    // ---- leaves
+    const int nleaf = (n + DC_LEAF - 1) / DC_LEAF;
+    std::vector<int> bs(nleaf + 1);
+    for (int l = 0; l <= nleaf; l++) bs[l] = (int)((long long)n * l / nleaf);
+    for (int l = 1; l < nleaf; l++) { const double b = fabs(e[bs[l] - 1]); d[bs[l] - 1] -= b; d[bs[l]] -= b; }
+    int maxleaf = 0;
+    for (int l = 0; l < nleaf; l++) maxleaf = std::max(maxleaf, bs[l + 1] - bs[l]);
+    std::vector<double> S((size_t)n * maxleaf, 0.0);
+    std::vector<int> itab(3 * (size_t)n + 16, 0);
+    int *leaf_start = itab.data(), *leaf_size = itab.data() + n, *leaf_of_row = itab.data() + 2 * n;
+    for (int l = 0; l < nleaf; l++) {
+        const int s = bs[l], m = bs[l + 1] - bs[l];
+        std::vector<double> dd(d.begin() + s, d.begin() + s + m), ee(m, 0.0), Zl((size_t)m * m);
+        for (int i = 0; i + 1 < m; i++) ee[i] = e[s + i];
+        if (host_tql2(m, dd.data(), ee.data(), Zl.data(), m) != 0) { set_error("stedc: leaf QL did not converge"); return PG_EINVAL; }
+        for (int i = 0; i < m; i++) { d[s + i] = dd[i]; for (int j = 0; j < m; j++) S[(size_t)(s + i) * maxleaf + j] = Zl[(size_t)i * m + j]; }
+        leaf_start[l] = s; leaf_size[l] = m;
+        for (int i = 0; i < m; i++) leaf_of_row[s + i] = l;
+    }
+    PG_HIP(hipMemsetAsync(wk.Qa, 0, (size_t)n * n * 8, st));
+    PG_HIP(hipMemsetAsync(wk.Qb, 0, (size_t)n * n * 8, st));
+    PG_HIP(hipMemcpyAsync(wk.S, S.data(), S.size() * 8, hipMemcpyHostToDevice, st));
+    PG_HIP(hipMemcpyAsync(wk.ibuf, itab.data(), 3 * (size_t)n * 4, hipMemcpyHostToDevice, st));
+    scatter_leaves_kernel<<<(unsigned)(((size_t)n * maxleaf + 255) / 256), 256, 0, st>>>(n, maxleaf, wk.S, wk.ibuf, wk.ibuf + n, wk.ibuf + 2 * n, wk.Qa);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipStreamSynchronize(st));   // host staging buffers go out of scope below
+
+    double *Qin = wk.Qa, *Qout = wk.Qb;
+    std::vector<int> blocks(bs);   // boundaries of the current level
+    std::vector<double> zhost(n), dnew(n);
+    std::vector<int> zrow(n), colbuf(n);
+    while (blocks.size() > 2) {
+        const int nb = (int)blocks.size() - 1;
+        std::vector<MergePlan> plans;
+        std::fill(zrow.begin(), zrow.end(), -1);
+        for (int b = 0; b + 1 < nb; b += 2) {
+            MergePlan mp; mp.s = blocks[b]; mp.n1 = blocks[b + 1] - blocks[b]; mp.nm = blocks[b + 2] - blocks[b];
+            for (int i = 0; i < mp.nm; i++) zrow[mp.s + i] = (i < mp.n1) ? (mp.s + mp.n1 - 1) : (mp.s + mp.n1);
+            plans.push_back(std::move(mp));
+        }
+        PG_HIP(hipMemcpyAsync(wk.ibuf, zrow.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        gather_z_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, Qin, wk.ibuf, wk.z);
+        PG_HIP(hipMemcpyAsync(zhost.data(), wk.z, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        PG_HIP(hipStreamSynchronize(st));
+        size_t rot_total = 0;
+        for (auto &mp : plans) {
+            plan_merge(mp, d.data() + mp.s, zhost.data() + mp.s, e[mp.s + mp.n1 - 1]);
+            for (int i = 0; i < mp.nm; i++) colbuf[mp.s + i] = mp.col[i];
+            rot_total += mp.rots.size();
+        }
+        std::vector<Rot> allrots; allrots.reserve(rot_total + 1);
+        std::vector<double> dlw(2 * (size_t)n, 0.0);
+        for (auto &mp : plans) {
+            for (auto &r : mp.rots) allrots.push_back(r);
+            for (int i = 0; i < mp.k; i++) { dlw[mp.s + i] = mp.dl[i]; dlw[(size_t)n + mp.s + i] = mp.w[i]; }
+        }
+        PG_HIP(hipMemcpyAsync(wk.ibuf + n, colbuf.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        if (!allrots.empty()) PG_HIP(hipMemcpyAsync(wk.rots, allrots.data(), allrots.size() * sizeof(Rot), hipMemcpyHostToDevice, st));
+        PG_HIP(hipMemcpyAsync(wk.dl, dlw.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+        PG_HIP(hipMemcpyAsync(wk.w, dlw.data() + n, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        size_t roff = 0;
+        for (auto &mp : plans) {
+            const int nm = mp.nm, k = mp.k, s = mp.s;
+            if (!mp.rots.empty()) {
+                givens_kernel<<<(nm + 255) / 256, 256, 0, st>>>(n, s, nm, Qin, wk.rots + roff, (int)mp.rots.size());
+                roff += mp.rots.size();
+            }
+            permute_cols_kernel<<<(unsigned)(((size_t)nm * nm + 255) / 256), 256, 0, st>>>(n, s, nm, k, Qin, wk.ibuf + n + s, wk.Tp, Qout);
+            if (k > 0) {
+                secular_kernel<<<(k + 255) / 256, 256, 0, st>>>(k, wk.dl + s, wk.w + s, mp.rho, wk.Um, wk.dnew + s);
+                zhat_kernel<<<(k + 3) / 4, 256, 0, st>>>(k, wk.dl + s, wk.w + s, wk.Um, wk.zh);
+                uvec_kernel<<<(k + 255) / 256, 256, 0, st>>>(k, wk.zh, wk.Um);
+                int rc = dgemm(ctx, false, nm, k, k, 1.0, wk.Tp, k, wk.Um, k, 0.0, Qout + (size_t)s * n + s, n);
+                if (rc) return rc;
+            }
+            PG_HIP(hipGetLastError());
+        }
+        std::vector<int> nblocks;
+        for (int b = 0; b + 1 < nb; b += 2) nblocks.push_back(blocks[b]);
+        if (nb % 2 == 1) {   // odd block carried to the next level unchanged
+            const int s = blocks[nb - 1], m = blocks[nb] - s;
+            copy_block_kernel<<<(unsigned)(((size_t)m * m + 255) / 256), 256, 0, st>>>(n, s, m, Qin, Qout);
+            nblocks.push_back(s);
+        }
+        nblocks.push_back(n);
+        PG_HIP(hipMemcpyAsync(dnew.data(), wk.dnew, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        PG_HIP(hipStreamSynchronize(st));
+        for (auto &mp : plans) {
+            for (int i = 0; i < mp.k; i++) d[mp.s + i] = dnew[mp.s + i];
+            for (int i = mp.k; i < mp.nm; i++) d[mp.s + i] = mp.ddefl[i - mp.k];
+        }
+        blocks.swap(nblocks);
+        std::swap(Qin, Qout);
+    }
+    // ---- final ascending order
+    std::vector<int> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return d[a] < d[b]; });
+    evals.resize(n);
+    for (int i = 0; i < n; i++) evals[i] = d[idx[i]];
+    PG_HIP(hipMemcpyAsync(wk.ibuf, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    permute_final_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n, Qin, wk.ibuf, Qout);
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipStreamSynchronize(st));
+    *Zout = Qout;
+    return PG_OK;
+}
+
+static int stedc_alloc(int n, StedcWork &wk)
+{
+    int rc = PG_OK;
+    double **bufs[] = {&wk.Qa, &wk.Qb, &wk.Tp, &wk.Um, &wk.z, &wk.dnew, &wk.dl, &wk.w, &wk.zh, &wk.S};
+    size_t sizes[] = {(size_t)n * n, (size_t)n * n, (size_t)n * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)n, (size_t)n, (size_t)n * (DC_LEAF + 1)};
+    for (int k = 0; k < 10 && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
+    if (!rc && hipMalloc(&wk.ibuf, (3 * (size_t)n + 16) * 4) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
+    if (!rc && hipMalloc(&wk.rots, ((size_t)n + 1) * sizeof(Rot)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
+    return rc;
+}
+static void stedc_free(StedcWork &wk)
+{
+    for (double *p : {wk.Qa, wk.Qb, wk.Tp, wk.Um, wk.z, wk.dnew, wk.dl, wk.w, wk.zh, wk.S}) if (p) (void)hipFree(p);
+    if (wk.ibuf) (void)hipFree(wk.ibuf);
+    if (wk.rots) (void)hipFree(wk.rots);
+    wk = StedcWork{};
+}
+
+static int alloc_d(double **p, size_t count)
+{
+    hipError_t e = hipMalloc(p, (count ? count : 1) * sizeof(double));
+    if (e != hipSuccess) { set_error("hipMalloc(%zu doubles) failed: %s", count, hipGetErrorString(e)); *p = nullptr; return PG_ENOMEM; }
+    return PG_OK;
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+// ---- internal test hooks (not part of include/pygemma_hip.h) -----------------------------------------
+extern "C" int pgx_dgemm_dev(pg_ctx *ctx, int transA, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                             const double *B, int64_t ldb, double beta, double *C, int64_t ldc)
+{
+    PG_REQUIRE(ctx && A && B && C, "pgx_dgemm_dev: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
+    return dgemm(ctx, transA != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+}
+
+extern "C" int pgx_sytrd_dev(pg_ctx *ctx, int64_t n64, const float *K, double *d, double *e, double *tau, double *Vall)
+{
+    PG_REQUIRE(ctx && K && d && e && tau && Vall && n64 >= 2 && n64 <= 65536, "pgx_sytrd_dev: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    const int n = (int)n64;
+    SytrdWork w;
+    int rc = PG_OK;
+    double **bufs[] = {&w.A, &w.P, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial};
+    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, (size_t)n / 256 + 2};
+    for (int k = 0; k < 8 && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
+    w.Vall = Vall; w.d = d; w.e = e; w.tau = tau;
+    if (!rc) {
+        sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, ctx->stream>>>(n, K, w.A);
+        rc = sytrd_device(ctx, n, w);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int k = 0; k < 8; k++) if (*bufs[k]) (void)hipFree(*bufs[k]);
+    return rc;
+}
+
+extern "C" int pgx_stedc_dev(pg_ctx *ctx, int64_t n64, const double *d_host, const double *e_host, double *evals_host, double *Z_dev)
+{
+    PG_REQUIRE(ctx && d_host && e_host && evals_host && Z_dev && n64 >= 1 && n64 <= 65536, "pgx_stedc_dev: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    const int n = (int)n64;
+    StedcWork wk;
+    int rc = stedc_alloc(n, wk);
+    std::vector<double> ev;
+    double *Z = nullptr;
+    if (!rc) rc = stedc_device(ctx, n, d_host, e_host, ev, wk, &Z);
+    if (!rc) {
+        for (int i = 0; i < n; i++) evals_host[i] = ev[i];
+        hipError_t e2 = hipMemcpyAsync(Z_dev, Z, (size_t)n * n * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e2 != hipSuccess) { set_error("copy failed"); rc = PG_EHIP; }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    stedc_free(wk);
+    return rc;
+}
+
+// compact-WY factor of a block of reflectors (forward, columnwise):  H_0 ... H_{m-1} = I - V T V'
+// G = V'V (m x m, ld NB).  T upper triangular (ld NB).  One workgroup.
+__global__ __launch_bounds__(64) void larft_kernel(int m, const double *G, const double *tau, double *T)
+{
+    __shared__ double Ts[NB][NB + 1];
+    const int i = threadIdx.x;
+    for (int j = 0; j < NB; j++) if (i < NB) Ts[i][j] = 0.0;
+    __syncthreads();
+    for (int j = 0; j < m; j++) {
+        const double tj = tau[j];
+        double v = 0.0;
+        if (i < j) {
+            for (int l = i; l < j; l++) v += Ts[i][l] * G[(size_t)l * NB + j];
+            v *= -tj;
+        }
+        __syncthreads();
+        if (i < j) Ts[i][j] = v;
+        if (i == j) Ts[j][j] = tj;
+        __syncthreads();
+    }
+    for (int j = 0; j < NB; j++) if (i < NB) T[(size_t)i * NB + j] = Ts[i][j];
+}
+
+__global__ void finalize_kernel(long long n, const double *X, const double *ev, float *U32, float *ev32)
+{
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n * n && U32) U32[idx] = (float)X[idx];
+    if (idx < n && ev32) ev32[idx] = (float)fmax(ev[idx], 0.0);   // lmm.py:157 np.maximum(0.0, eigenVals), then float32
+}
+
+// Z <- Q Z with Q = H_0 H_1 ... H_{n-2} (reflectors in Vall columns, scalars tau on the device)
+static int backtransform_device(pg_ctx *ctx, int n, const double *Vall, const double *tau, double *Z, double *G, double *T, double *W, double *W2)
+{
+    hipStream_t s = ctx->stream;
+    const int nref = n - 1;
+    const int nblk = (nref + NB - 1) / NB;
+    for (int b = nblk - 1; b >= 0; b--) {
+        const int i0 = b * NB, m = std::min(NB, nref - i0);
+        const double *V = Vall + (size_t)i0 * n + i0;   // rows i0.., columns i0..i0+m-1 (row i0 itself is zero)
+        const long long rows = n - i0;
+        int rc = dgemm(ctx, true, m, m, rows, 1.0, V, n, V, n, 0.0, G, NB);
+        if (rc) return rc;
+        larft_kernel<<<1, 64, 0, s>>>(m, G, tau + i0, T);
+        PG_HIP(hipGetLastError());
+        rc = dgemm(ctx, true, m, n, rows, 1.0, V, n, Z + (size_t)i0 * n, n, 0.0, W, n);          // W  = V' Z
+        if (!rc) rc = dgemm(ctx, false, m, n, m, 1.0, T, NB, W, n, 0.0, W2, n);                  // W2 = T W
+        if (!rc) rc = dgemm(ctx, false, rows, n, m, -1.0, V, n, W2, n, 1.0, Z + (size_t)i0 * n, n);  // Z -= V W2
+        if (rc) return rc;
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *evals, float *U, double *evals64, double *U64)
+{
+    PG_REQUIRE(ctx && K && (evals || evals64), "pg_syevd_dev: NULL argument");
+    PG_REQUIRE(n64 >= 1 && n64 <= 65536, "pg_syevd_dev: n=%lld out of range", (long long)n64);
+    PG_HIP(hipSetDevice(ctx->device));
+    const int n = (int)n64;
+    hipStream_t st = ctx->stream;
+    SytrdWork w;
+    StedcWork wk;
+    double *G = nullptr, *T = nullptr, *W = nullptr, *W2 = nullptr, *dev_ev = nullptr;
+    int rc = PG_OK;
+    double **bufs[] = {&w.A, &w.P, &w.Vall, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial, &w.d, &w.e, &w.tau, &G, &T, &W, &W2, &dev_ev};
+    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, (size_t)n / 256 + 2,
+                      (size_t)n, (size_t)n, (size_t)n, (size_t)NB * NB, (size_t)NB * NB, (size_t)NB * n, (size_t)NB * n, (size_t)n};
+    const int nbuf = (int)(sizeof(sizes) / sizeof(sizes[0]));
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(st);
+        for (int k = 0; k < nbuf; k++) if (*bufs[k]) { (void)hipFree(*bufs[k]); *bufs[k] = nullptr; }
+        stedc_free(wk);
+    };
+    for (int k = 0; k < nbuf && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
+    if (!rc) rc = stedc_alloc(n, wk);
+    if (rc) { cleanup(); return rc; }
+    std::vector<double> hd(n), he(n, 0.0), ev;
+    double *Z = nullptr;
+    if (n == 1) {
+        // trivial: T = K
+        sym_from_lower_kernel<<<1, 256, 0, st>>>(1, K, w.A);
+        if (hipMemcpyAsync(hd.data(), w.A, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = PG_EHIP;
+    } else {
+        PG_HIP(hipMemsetAsync(w.Vall, 0, (size_t)n * n * 8, st));
+        PG_HIP(hipMemsetAsync(w.tau, 0, (size_t)n * 8, st));
+        sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n, K, w.A);
+        rc = sytrd_device(ctx, n, w);
+        if (!rc) {
+            if (hipMemcpyAsync(hd.data(), w.d, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(he.data(), w.e, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { set_error("pg_syevd_dev: reading T back failed: %s", hipGetErrorString(hipGetLastError())); rc = PG_EHIP; }
+        }
+    }
+    if (!rc) rc = stedc_device(ctx, n, hd.data(), he.data(), ev, wk, &Z);
+    if (!rc && n > 1) rc = backtransform_device(ctx, n, w.Vall, w.tau, Z, G, T, W, W2);
+    if (!rc) {
+        hipError_t e1 = hipMemcpyAsync(dev_ev, ev.data(), (size_t)n * 8, hipMemcpyHostToDevice, st);
+        if (e1 != hipSuccess) rc = PG_EHIP;
+        if (!rc) {
+            finalize_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n, Z, dev_ev, U, evals);
+            if (evals64 && hipMemcpyAsync(evals64, dev_ev, (size_t)n * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = PG_EHIP;
+            if (U64 && hipMemcpyAsync(U64, Z, (size_t)n * n * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = PG_EHIP;
+            if (hipGetLastError() != hipSuccess) rc = PG_EHIP;
+        }
+        if (rc == PG_EHIP) set_error("pg_syevd_dev: output stage failed");
+    }
+    cleanup();   // synchronises the stream: outputs are complete on return
+    return rc;
 }

@@ -74,3 +74,32 @@ def rotate(U, X, ctx=None, ldx=None):
     finally:
         if own:
             ctx.close()
+
+
+def syevd(K, ctx=None, want64=False):
+    """scipy.linalg.eigh(K) (lmm/lmm.py:152) on the GPU: lower triangle of K (n,n) float32 ->
+    (evals f32 ascending clamped >= 0, U f32 with eigenvector j in column j[, evals f64, U f64])."""
+    L = _lib.load()
+    own = ctx is None
+    ctx = ctx or _lib.Context(0)
+    try:
+        K = _f32(K)
+        n = K.shape[0]
+        assert K.shape == (n, n)
+        dK = ctx.to_device(K)
+        dev, dU = ctx.alloc(n * 4), ctx.alloc(n * n * 4)
+        d64 = ctx.alloc(n * 8) if want64 else None
+        U64 = ctx.alloc(n * n * 8) if want64 else None
+        _lib.check(L.pg_syevd_dev(ctx.handle, n, dK.ptr, dev.ptr, dU.ptr, d64.ptr if want64 else None,
+                                  U64.ptr if want64 else None), "pg_syevd_dev")
+        ctx.sync()
+        out = [dev.download((n,), np.float32), dU.download((n, n), np.float32)]
+        if want64:
+            out += [d64.download((n,), np.float64), U64.download((n, n), np.float64)]
+        for b in (dK, dev, dU, d64, U64):
+            if b is not None:
+                b.free()
+        return tuple(out)
+    finally:
+        if own:
+            ctx.close()

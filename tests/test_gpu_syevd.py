@@ -1,0 +1,128 @@
+"""GPU tests of the fp64 eigensolver pieces and of pg_syevd_dev (SURVEY 8c Tier B: invariants, not
+agreement with the reference's float32 LAPACK)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pygemma_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _kin(n, seed=0):
+    from pygemma_amd import synth
+    return synth.panel(n, 4, 1, seed=seed)["K"]
+
+
+@pytest.mark.parametrize("ta", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 8), (200, 130, 77), (513, 260, 128), (64, 1000, 300)])
+def test_dgemm_mfma_f64(ta, M, N, K, ctx):
+    from pygemma_amd import _lib
+    L = _lib.load()
+    L.pgx_dgemm_dev.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_int64,
+                                C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int64]
+    rng = np.random.default_rng(M + N + K + ta)
+    A = rng.standard_normal((K, M) if ta else (M, K))
+    B = rng.standard_normal((K, N))
+    Cm = rng.standard_normal((M, N))
+    dA, dB, dC = ctx.to_device(A), ctx.to_device(B), ctx.to_device(Cm)
+    _lib.check(L.pgx_dgemm_dev(ctx.handle, ta, M, N, K, -1.5, dA.ptr, A.shape[1], dB.ptr, N, 0.5, dC.ptr, N), "dgemm")
+    ctx.sync()
+    got = dC.download((M, N), np.float64)
+    ref = -1.5 * ((A.T if ta else A) @ B) + 0.5 * Cm
+    assert np.abs(got - ref).max() <= 1e-12 * np.sqrt(K) * 10
+
+
+@pytest.mark.parametrize("n", [5, 64, 65, 130, 300, 777])
+def test_sytrd_similarity(n, ctx):
+    """T = Q' K Q: the tridiagonal's eigenvalues equal K's (fp64), and Q built from the reflectors is
+    orthogonal with Q T Q' = K."""
+    import scipy.linalg as sl
+    from pygemma_amd import _lib
+    L = _lib.load()
+    L.pgx_sytrd_dev.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+    K = _kin(n, seed=n)
+    dK = ctx.to_device(K)
+    dd, de, dt, dV = ctx.alloc(n * 8), ctx.alloc(n * 8), ctx.alloc(n * 8), ctx.alloc(n * n * 8)
+    _lib.check(L.pgx_sytrd_dev(ctx.handle, n, dK.ptr, dd.ptr, de.ptr, dt.ptr, dV.ptr), "sytrd")
+    d, e, tau = dd.download((n,), np.float64), de.download((n,), np.float64)[: n - 1], dt.download((n,), np.float64)[: n - 1]
+    V = dV.download((n, n), np.float64)
+    K64 = np.tril(K.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
+    ref = np.linalg.eigvalsh(K64)
+    got = sl.eigvalsh_tridiagonal(d, e)
+    assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    if n <= 300:
+        Q = np.eye(n)
+        for i in range(n - 1):
+            v = V[:, i]
+            Q = Q - tau[i] * np.outer(Q @ v, v)
+        T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+        assert np.abs(Q.T @ Q - np.eye(n)).max() <= 1e-13 * n
+        assert np.abs(Q @ T @ Q.T - K64).max() <= 1e-13 * n * np.abs(K64).max()
+
+
+def _tridiags():
+    rng = np.random.default_rng(42)
+    out = {}
+    for n in (1, 2, 3, 31, 32, 33, 64, 100, 257, 1000):
+        out[f"rand{n}"] = (rng.standard_normal(n), rng.standard_normal(max(n - 1, 0)))
+    n = 301
+    out["toeplitz121"] = (np.full(n, 2.0), np.full(n - 1, -1.0))
+    m = 10
+    w = np.abs(np.arange(-m, m + 1)).astype(float)
+    out["wilkinson21"] = (w, np.ones(2 * m))
+    # glued Wilkinson: tight clusters
+    d = np.concatenate([w] * 8); e = np.ones(d.size - 1); e[2 * m::2 * m + 1] = 1e-8
+    out["glued_wilkinson"] = (d, e[: d.size - 1])
+    out["graded"] = (10.0 ** -np.arange(0, 120, dtype=float) ** 0.5, 10.0 ** -np.arange(1, 120, dtype=float) ** 0.5)
+    out["zero_offdiag"] = (rng.standard_normal(200), np.where(rng.random(199) < 0.3, 0.0, rng.standard_normal(199)))
+    out["identity"] = (np.ones(150), np.zeros(149))
+    return out
+
+
+@pytest.mark.parametrize("name", list(_tridiags().keys()))
+def test_stedc_divide_and_conquer(name, ctx):
+    """T = Z diag(lam) Z' for hard tridiagonals: eigenvalues vs LAPACK (fp64), residual and orthogonality."""
+    import scipy.linalg as sl
+    from pygemma_amd import _lib
+    L = _lib.load()
+    L.pgx_stedc_dev.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 4
+    d, e = _tridiags()[name]
+    n = d.size
+    d = np.ascontiguousarray(d, np.float64); e2 = np.ascontiguousarray(np.concatenate([e, [0.0]]), np.float64)
+    ev = np.empty(n)
+    dZ = ctx.alloc(n * n * 8)
+    _lib.check(L.pgx_stedc_dev(ctx.handle, n, d.ctypes.data, e2.ctypes.data, ev.ctypes.data, dZ.ptr), "stedc")
+    Z = dZ.download((n, n), np.float64)
+    T = np.diag(d) + (np.diag(e, 1) + np.diag(e, -1) if n > 1 else 0)
+    ref = np.linalg.eigvalsh(T) if n > 1 else d.copy()
+    scale = max(np.abs(T).max(), 1e-300)
+    assert np.all(np.diff(ev) >= 0)
+    assert np.abs(ev - ref).max() <= 2e-14 * scale * max(1, np.sqrt(n))
+    assert np.abs(Z.T @ Z - np.eye(n)).max() <= 5e-14 * max(1, np.sqrt(n))
+    assert np.abs(T @ Z - Z * ev).max() <= 5e-14 * scale * max(1, np.sqrt(n))
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 129, 300, 1000, 1940])
+def test_syevd_invariants(n, ctx):
+    """pg_syevd_dev (SURVEY 8c Tier B): ||K - U L U'||_F/||K||_F <= 1e-12 sqrt(n), |U'U - I|_max <= 1e-12,
+    eigenvalues vs host LAPACK dsyevd within 1e-12 lambda_max; f32 outputs = clamp + cast of the f64 ones."""
+    from pygemma_amd import ops
+    K = _kin(n, seed=100 + n) if n > 2 else np.array([[2.0, 0], [0.5, 1.0]], np.float32)[:n, :n]
+    K64 = np.tril(K.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
+    ev32, U32, ev, U = ops.syevd(K, ctx=ctx, want64=True)
+    ref = np.linalg.eigvalsh(K64)
+    lmax = max(np.abs(ref).max(), 1e-300)
+    assert np.abs(ev - ref).max() <= 1e-12 * lmax
+    assert np.abs(U.T @ U - np.eye(n)).max() <= 1e-12
+    res = np.linalg.norm(K64 - (U * ev) @ U.T) / max(np.linalg.norm(K64), 1e-300)
+    assert res <= 1e-12 * np.sqrt(n)
+    assert (ev32 == np.maximum(ev, 0).astype(np.float32)).all() and (ev32 >= 0).all()
+    assert (U32 == U.astype(np.float32)).all()
