@@ -50,6 +50,14 @@ int pg_free(pg_ctx *ctx, void *dptr);
 int pg_memcpy_h2d(pg_ctx *ctx, void *dst, const void *src, size_t bytes);
 int pg_memcpy_d2h(pg_ctx *ctx, void *dst, const void *src, size_t bytes);
 int pg_memset(pg_ctx *ctx, void *dst, int value, size_t bytes);
+/* strided host -> device copy: `height` rows of `width` bytes (a column window of a row-major host matrix) */
+int pg_memcpy2d_h2d(pg_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height);
+
+/* HIP events on the context's stream (kernel timing for bench.py's roofline leg) */
+int pg_event_create(pg_ctx *ctx, void **event);
+int pg_event_destroy(pg_ctx *ctx, void *event);
+int pg_event_record(pg_ctx *ctx, void *event);
+int pg_event_elapsed_ms(pg_ctx *ctx, void *start, void *stop, float *ms); /* synchronises on `stop` */
 
 /* ---- H3-H10: the per-SNP operator -------------------------------------------------------
  * Replaces calculate() (lmm/lmm.py:461-495) and everything under it: calc_lambda_restricted
@@ -80,14 +88,21 @@ int pg_assoc(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const flo
 /* scipy.stats.f.sf(F, 1, dfd) (lmm/lmm.py:482) for a device vector */
 int pg_fdist_sf_dev(pg_ctx *ctx, int64_t count, const double *F, double dfd, double *pval);
 
-/* (n x p row-major) -> SNP-major (p x ldx), pad columns [n, ldx) zero-filled */
-int pg_transpose_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *X_n_by_p, float *Xr, int64_t ldx);
+/* (n x p row-major, row stride ldX >= p) -> SNP-major (p x ldx), pad columns [n, ldx) zero-filled */
+int pg_transpose_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *X_n_by_p, int64_t ldX, float *Xr, int64_t ldx);
 
 /* ---- H2: rotation  X <- U' X  (lmm/lmm.py:243-246, OpenBLAS sgemm in the reference) ---------
- * U (n x n) row-major with eigenvector j in COLUMN j (scipy.linalg.eigh's convention); X in the
- * reference layout (n x p); output SNP-major Xr (p x ldx): Xr[g*ldx + k] = sum_i U[i*n + k] * X[i*p + g].
- * fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate — the reference's own precision. */
-int pg_rotate_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, const float *X_n_by_p, float *Xr, int64_t ldx);
+ * U (n x n, row stride ldU) row-major with eigenvector j in COLUMN j (scipy.linalg.eigh's convention); X in
+ * the reference layout (n x p, row stride ldX >= p: a column window of a wider matrix is fine); output
+ * SNP-major Xr (p x ldx): Xr[g*ldx + k] = sum_i U[i*ldU + k] * X[i*ldX + g], pad columns [n, ldx) zeroed.
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate in sample order i = 0..n-1 — the reference's precision. */
+int pg_rotate_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU, const float *X_n_by_p, int64_t ldX,
+                  float *Xr, int64_t ldx);
+
+/* ---- N3: relatedness matrix from standardised genotypes, K = G G' / p_k
+ * (experiments/animal_gwas/run_gwas.py:45-55, tests/test_pygemma.py:184-192).  Gt is the SNP-major (p_k x ldg)
+ * image of G (n x p_k), e.g. from pg_transpose_dev; K (n x n, row-major) float32, both triangles written. */
+int pg_kinship_dev(pg_ctx *ctx, int64_t n, int64_t p_k, const float *Gt, int64_t ldg, float *K);
 
 /* ---- H1: eigendecomposition of K (lmm/lmm.py:151-162 / :196-207, scipy.linalg.eigh = LAPACK ssyevr)
  * Reads the LOWER triangle of row-major K (n x n, float32, device).  Computes in fp64; delivers ascending

@@ -15,7 +15,8 @@ _lib = None
 SYMBOLS = [
     "pg_last_error", "pg_version", "pg_device_count", "pg_ctx_create", "pg_ctx_create_on_stream",
     "pg_ctx_destroy", "pg_ctx_sync", "pg_ctx_device", "pg_malloc", "pg_free", "pg_memcpy_h2d", "pg_memcpy_d2h",
-    "pg_memset", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev", "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev",
+    "pg_memset", "pg_memcpy2d_h2d", "pg_event_create", "pg_event_destroy", "pg_event_record", "pg_event_elapsed_ms",
+    "pg_kinship_dev", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev", "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev",
 ]
 
 
@@ -50,12 +51,19 @@ def load():
     L.pg_assoc_dev.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]
     L.pg_assoc.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.pg_fdist_sf_dev.argtypes = [vp, i64, vp, C.c_double, vp]
-    L.pg_transpose_dev.argtypes = [vp, i64, i64, vp, vp, i64]
-    L.pg_rotate_dev.argtypes = [vp, i64, i64, vp, vp, vp, i64]
+    L.pg_transpose_dev.argtypes = [vp, i64, i64, vp, i64, vp, i64]
+    L.pg_rotate_dev.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp, i64]
+    L.pg_kinship_dev.argtypes = [vp, i64, i64, vp, i64, vp]
+    L.pg_memcpy2d_h2d.argtypes = [vp, vp, sz, vp, sz, sz, sz]
+    L.pg_event_create.argtypes = [vp, C.POINTER(vp)]
+    L.pg_event_destroy.argtypes = [vp, vp]
+    L.pg_event_record.argtypes = [vp, vp]
+    L.pg_event_elapsed_ms.argtypes = [vp, vp, vp, C.POINTER(C.c_float)]
     L.pg_syevd_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     for name in ("pg_ctx_create", "pg_ctx_create_on_stream", "pg_ctx_sync", "pg_ctx_device", "pg_malloc", "pg_free",
                  "pg_memcpy_h2d", "pg_memcpy_d2h", "pg_memset", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev",
-                 "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev"):
+                 "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev", "pg_memcpy2d_h2d", "pg_event_create", "pg_event_destroy",
+                 "pg_event_record", "pg_event_elapsed_ms", "pg_kinship_dev"):
         getattr(L, name).restype = i32
     _lib = L
     return L

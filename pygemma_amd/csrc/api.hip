@@ -211,6 +211,43 @@ extern "C" int pg_memset(pg_ctx *ctx, void *dst, int value, size_t bytes)
     return PG_OK;
 }
 
+extern "C" int pg_memcpy2d_h2d(pg_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height)
+{
+    PG_REQUIRE(ctx && dst && src && dpitch >= width && spitch >= width, "pg_memcpy2d_h2d: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    PG_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return PG_OK;
+}
+extern "C" int pg_event_create(pg_ctx *ctx, void **event)
+{
+    PG_REQUIRE(ctx && event, "pg_event_create: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
+    hipEvent_t e;
+    PG_HIP(hipEventCreate(&e));
+    *event = (void *)e;
+    return PG_OK;
+}
+extern "C" int pg_event_destroy(pg_ctx *ctx, void *event)
+{
+    PG_REQUIRE(ctx, "pg_event_destroy: NULL ctx");
+    if (event) PG_HIP(hipEventDestroy((hipEvent_t)event));
+    return PG_OK;
+}
+extern "C" int pg_event_record(pg_ctx *ctx, void *event)
+{
+    PG_REQUIRE(ctx && event, "pg_event_record: NULL argument");
+    PG_HIP(hipEventRecord((hipEvent_t)event, ctx->stream));
+    return PG_OK;
+}
+extern "C" int pg_event_elapsed_ms(pg_ctx *ctx, void *start, void *stop, float *ms)
+{
+    PG_REQUIRE(ctx && start && stop && ms, "pg_event_elapsed_ms: NULL argument");
+    PG_HIP(hipEventSynchronize((hipEvent_t)stop));
+    PG_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return PG_OK;
+}
+
 // host-pointer convenience around pg_assoc_dev: X in the reference layout (n x p), copied in SNP batches
 extern "C" int pg_assoc(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
                         const float *X, int grid, float *beta, float *se, float *tau, float *lambda, double *F,
@@ -244,7 +281,7 @@ extern "C" int pg_assoc(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d
     PG_TRY(hipMemcpyAsync(dW, Wr, (size_t)n * c * 4, hipMemcpyHostToDevice, ctx->stream));
     PG_TRY(hipMemcpyAsync(dy, yr, n * 4, hipMemcpyHostToDevice, ctx->stream));
     PG_TRY(hipMemcpyAsync(dX, X, (size_t)n * p * 4, hipMemcpyHostToDevice, ctx->stream));
-    rc = pg_transpose_dev(ctx, n, p, dX, dXr, ldx);
+    rc = pg_transpose_dev(ctx, n, p, dX, p, dXr, ldx);
     if (!rc) rc = pg_assoc_dev(ctx, n, c, p, dd, dW, dy, dXr, ldx, grid, dout, dout + p, dout + 2 * p, dout + 3 * p, dF,
                                pval ? dF + p : nullptr, dstats);
     if (rc) { cleanup(); return rc; }

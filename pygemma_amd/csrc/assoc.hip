@@ -605,14 +605,14 @@ __global__ void build_fixed_kernel(int n, int npad, int c, int rowf, const float
 }
 
 // (n x p row-major) -> SNP-major (p x ldx), 32x32 LDS tile transpose, pad zeroed
-__global__ __launch_bounds__(256) void transpose_kernel(long long n, long long p, const float *X, float *Xr, long long ldx)
+__global__ __launch_bounds__(256) void transpose_kernel(long long n, long long p, const float *X, long long ldX, float *Xr, long long ldx)
 {
     __shared__ float tile[32][33];
     const long long g0 = (long long)blockIdx.x * 32, i0 = (long long)blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     for (int r = ty; r < 32; r += 8) {
         long long i = i0 + r, g = g0 + tx;
-        tile[r][tx] = (i < n && g < p) ? X[(size_t)i * p + g] : 0.0f;
+        tile[r][tx] = (i < n && g < p) ? X[(size_t)i * ldX + g] : 0.0f;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
@@ -659,12 +659,12 @@ extern "C" int pg_fdist_sf_dev(pg_ctx *ctx, int64_t count, const double *F, doub
     return PG_OK;
 }
 
-extern "C" int pg_transpose_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *X, float *Xr, int64_t ldx)
+extern "C" int pg_transpose_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *X, int64_t ldX, float *Xr, int64_t ldx)
 {
-    PG_REQUIRE(ctx && X && Xr && n > 0 && p > 0 && ldx >= n, "pg_transpose_dev: bad arguments");
+    PG_REQUIRE(ctx && X && Xr && n > 0 && p > 0 && ldx >= n && ldX >= p, "pg_transpose_dev: bad arguments");
     PG_HIP(hipSetDevice(ctx->device));
     dim3 grid((unsigned)((p + 31) / 32), (unsigned)((ldx + 31) / 32));
-    transpose_kernel<<<grid, 256, 0, ctx->stream>>>(n, p, X, Xr, ldx);
+    transpose_kernel<<<grid, 256, 0, ctx->stream>>>(n, p, X, ldX, Xr, ldx);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }

@@ -22,10 +22,12 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int RBM = 128, RBN = 128, RBK = 16, RGROUP = 8;
 
+// out[g][k] = scale * sum_{i<kdim} X[i*ldX + g] * U[i*ldU + k]   g < p (M), k < ncol (N); columns [ncol, ldx) zeroed
 struct RotParams {
-    long long n, p, ldx;
+    long long kdim, ncol, p, ldx, ldU, ldX;
     const float *U, *X;
     float *Xr;
+    float scale;
     int tiles_m, tiles_n;
 };
 
@@ -77,12 +79,12 @@ __global__ __launch_bounds__(256, 2) void rotate_kernel(RotParams rp)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
-    const int KT = (int)((rp.n + RBK - 1) / RBK);
+    const int KT = (int)((rp.kdim + RBK - 1) / RBK);
     float4 ra[2], rb[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        ra[h] = load4<VEC>(rp.X, h * 8 + lrow, rp.p, m0 + lcol, rp.n, rp.p);
-        rb[h] = load4<VEC>(rp.U, h * 8 + lrow, rp.n, n0 + lcol, rp.n, rp.n);
+        ra[h] = load4<VEC>(rp.X, h * 8 + lrow, rp.ldX, m0 + lcol, rp.kdim, rp.p);
+        rb[h] = load4<VEC>(rp.U, h * 8 + lrow, rp.ldU, n0 + lcol, rp.kdim, rp.ncol);
     }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -96,8 +98,8 @@ __global__ __launch_bounds__(256, 2) void rotate_kernel(RotParams rp)
             const long long k0 = (long long)(kt + 1) * RBK;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                ra[h] = load4<VEC>(rp.X, k0 + h * 8 + lrow, rp.p, m0 + lcol, rp.n, rp.p);
-                rb[h] = load4<VEC>(rp.U, k0 + h * 8 + lrow, rp.n, n0 + lcol, rp.n, rp.n);
+                ra[h] = load4<VEC>(rp.X, k0 + h * 8 + lrow, rp.ldX, m0 + lcol, rp.kdim, rp.p);
+                rb[h] = load4<VEC>(rp.U, k0 + h * 8 + lrow, rp.ldU, n0 + lcol, rp.kdim, rp.ncol);
             }
         }
 #pragma unroll
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void rotate_kernel(RotParams rp)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const long long row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (row < rp.p && col < rp.ldx) rp.Xr[row * rp.ldx + col] = acc[i][j][e];
+                if (row < rp.p && col < rp.ldx) rp.Xr[row * rp.ldx + col] = rp.scale == 1.0f ? acc[i][j][e] : rp.scale * acc[i][j][e];
             }
         }
 }
@@ -139,21 +141,37 @@ __global__ __launch_bounds__(256, 2) void rotate_kernel(RotParams rp)
 
 using namespace pg;
 
-extern "C" int pg_rotate_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, const float *X, float *Xr, int64_t ldx)
+static int launch_tn(pg_ctx *ctx, long long kdim, long long ncol, long long p, const float *U, long long ldU, const float *X,
+                     long long ldX, float *out, long long ldx, float scale)
 {
-    PG_REQUIRE(ctx && U && X && Xr, "pg_rotate_dev: NULL argument");
-    PG_REQUIRE(n > 0 && p > 0 && ldx >= n && ldx <= (n + 127) / 128 * 128, "pg_rotate_dev: bad shape n=%lld p=%lld ldx=%lld (need n <= ldx <= roundup(n,128))",
-               (long long)n, (long long)p, (long long)ldx);
-    PG_HIP(hipSetDevice(ctx->device));
     RotParams rp{};
-    rp.n = n; rp.p = p; rp.ldx = ldx; rp.U = U; rp.X = X; rp.Xr = Xr;
+    rp.kdim = kdim; rp.ncol = ncol; rp.p = p; rp.ldx = ldx; rp.ldU = ldU; rp.ldX = ldX; rp.U = U; rp.X = X; rp.Xr = out; rp.scale = scale;
     rp.tiles_m = (int)((p + RBM - 1) / RBM);
-    rp.tiles_n = (int)((n + RBN - 1) / RBN);
+    rp.tiles_n = (int)((ncol + RBN - 1) / RBN);
     const long long T = (long long)rp.tiles_m * rp.tiles_n;
-    PG_REQUIRE(T < (1LL << 31), "pg_rotate_dev: too many tiles; rotate in SNP batches");
-    const bool vec = (n % 4 == 0) && (p % 4 == 0) && (((uintptr_t)U | (uintptr_t)X) % 16 == 0);
+    PG_REQUIRE(T < (1LL << 31), "rotate: too many tiles; process SNPs in batches");
+    const bool vec = (ldU % 4 == 0) && (ldX % 4 == 0) && (((uintptr_t)U | (uintptr_t)X) % 16 == 0);
     if (vec) rotate_kernel<4><<<dim3((unsigned)T), 256, 0, ctx->stream>>>(rp);
     else rotate_kernel<1><<<dim3((unsigned)T), 256, 0, ctx->stream>>>(rp);
     PG_HIP(hipGetLastError());
     return PG_OK;
+}
+
+extern "C" int pg_rotate_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU, const float *X, int64_t ldX,
+                             float *Xr, int64_t ldx)
+{
+    PG_REQUIRE(ctx && U && X && Xr, "pg_rotate_dev: NULL argument");
+    PG_REQUIRE(n > 0 && p > 0 && ldU >= n && ldX >= p && ldx >= n && ldx <= (n + 127) / 128 * 128,
+               "pg_rotate_dev: bad shape n=%lld p=%lld ldU=%lld ldX=%lld ldx=%lld (need n <= ldx <= roundup(n,128))",
+               (long long)n, (long long)p, (long long)ldU, (long long)ldX, (long long)ldx);
+    PG_HIP(hipSetDevice(ctx->device));
+    return launch_tn(ctx, n, n, p, U, ldU, X, ldX, Xr, ldx, 1.0f);
+}
+
+extern "C" int pg_kinship_dev(pg_ctx *ctx, int64_t n, int64_t p_k, const float *Gt, int64_t ldg, float *K)
+{
+    PG_REQUIRE(ctx && Gt && K && n > 0 && p_k > 0 && ldg >= n, "pg_kinship_dev: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    // K[a][b] = (1/p_k) sum_g Gt[g][a] Gt[g][b]
+    return launch_tn(ctx, p_k, n, n, Gt, ldg, Gt, ldg, K, n, (float)(1.0 / (double)p_k));
 }

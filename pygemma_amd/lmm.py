@@ -1,0 +1,182 @@
+"""lmm.pygemma(Y, X, W, K, snps=...) — drop-in for the reference's entry point (lmm/lmm.py:87-411) with
+everything under it running on MI355X through the C ABI (include/pygemma_hip.h):
+
+    eigh(K)                     -> pg_syevd_dev   (fp64 Householder + divide & conquer, lmm.py:152/197)
+    U.T @ X, U.T @ Y, U.T @ W   -> pg_rotate_dev  (fp32 MFMA GEMM, lmm.py:243-246)
+    Pool(nproc).imap(calculate) -> pg_assoc_dev   (wave-per-SNP fused lambda search + Wald test, lmm.py:378-403,461-495)
+    stats.f.sf                  -> on device      (lmm.py:482)
+
+Same signature, same casts to float32 (lmm.py:115-128), same output DataFrame schema (columns beta, se_beta,
+tau as float32; lambda, F_wald, p_wald as float64; SNPs as object when `snps` is given; lmm.py:403-409).
+`nproc` = number of GPUs to spread contiguous SNP blocks over, exactly like SampleIter's ceil(p/nproc)
+column blocks (lmm.py:427-434); results come back in block order = SNP order.
+There is no CPU fallback: without the HIP library or a GPU this raises.
+"""
+import threading
+import time
+
+import numpy as np
+import pandas as pd
+
+from . import _lib
+
+__all__ = ["pygemma", "SampleIter"]
+
+_BATCH_BYTES = 6 << 30   # device bytes for one SNP batch (raw block + rotated block)
+
+
+class SampleIter:
+    """Contiguous column blocks of ceil(p/nproc) SNPs (lmm/lmm.py:413-436) — here: one block per GPU."""
+
+    def __init__(self, p, nproc):
+        self.p, self.nproc = int(p), int(nproc)
+
+    def __iter__(self):
+        cols = int(np.ceil(self.p / self.nproc))
+        for r in range(self.nproc):
+            a, b = r * cols, min((r + 1) * cols, self.p)
+            if a < b:
+                yield a, b
+
+
+def _log(verbose, msg):
+    if verbose > 0:
+        print(f"[pygemma_amd] {msg}", flush=True)
+
+
+def _rotate_small(ctx, L, n, dU, A):
+    """U.T @ A for a narrow host matrix A (n,q) (Y and W): same MFMA kernel, SNP-major result transposed back."""
+    q = A.shape[1]
+    ldx = (n + 63) // 64 * 64
+    dA = ctx.to_device(np.ascontiguousarray(A, np.float32))
+    dO = ctx.alloc(q * ldx * 4)
+    _lib.check(L.pg_rotate_dev(ctx.handle, n, q, dU.ptr, n, dA.ptr, q, dO.ptr, ldx), "pg_rotate_dev")
+    ctx.sync()
+    out = dO.download((q, ldx), np.float32)[:, :n].T.copy()
+    dA.free(); dO.free()
+    return out
+
+
+def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs, verbose):
+    """One GPU: SNP columns [a,b) of X through (rotate | transpose) -> assoc, in batches."""
+    try:
+        L = _lib.load()
+        ctx = _lib.Context(device)
+        try:
+            ldx = (n + 63) // 64 * 64
+            dd, dW, dy = ctx.to_device(d), ctx.to_device(Wr), ctx.to_device(yr)
+            dU = ctx.to_device(U_host) if eigen else None
+            pb_max = max(256, int(_BATCH_BYTES // (4 * (n + ldx))) // 256 * 256)
+            pb_max = min(pb_max, b - a)
+            ldX = (pb_max + 3) // 4 * 4
+            dX = ctx.alloc(n * ldX * 4)
+            dXr = ctx.alloc(pb_max * ldx * 4)
+            dout = ctx.alloc(pb_max * 16)
+            dF = ctx.alloc(pb_max * 16)
+            p = X.shape[1]
+            for s in range(a, b, pb_max):
+                e = min(s + pb_max, b)
+                pb = e - s
+                _lib.check(L.pg_memcpy2d_h2d(ctx.handle, dX.ptr, ldX * 4, X.ctypes.data + 4 * s, p * 4, pb * 4, n), "pg_memcpy2d_h2d")
+                if eigen:
+                    _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dX.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
+                else:
+                    _lib.check(L.pg_transpose_dev(ctx.handle, n, pb, dX.ptr, ldX, dXr.ptr, ldx), "pg_transpose_dev")
+                _lib.check(L.pg_assoc_dev(ctx.handle, n, c, pb, dd.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, int(grid),
+                                          dout.ptr, dout.ptr + 4 * pb, dout.ptr + 8 * pb, dout.ptr + 12 * pb,
+                                          dF.ptr, dF.ptr + 8 * pb, None), "pg_assoc_dev")
+                ctx.sync()
+                res = dout.download((4, pb), np.float32)
+                FP = dF.download((2, pb), np.float64)
+                out["beta"][s:e], out["se_beta"][s:e], out["tau"][s:e] = res[0], res[1], res[2]
+                out["lambda"][s:e] = res[3].astype(np.float64)
+                out["F_wald"][s:e], out["p_wald"][s:e] = FP[0], FP[1]
+                _log(verbose, f"GPU {device}: SNPs [{s},{e}) done")
+        finally:
+            ctx.close()
+    except Exception as ex:  # surfaced by the caller; never swallowed
+        errs.append(ex)
+
+
+def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=False, grid=False, eigen=True, nproc=1):
+    """Per-SNP LMM association scan (GEMMA-style REML + Wald test) — signature of lmm/lmm.py:87.
+
+    Y (n,1) phenotype; X (n,p) genotypes; W (n,c) covariates; K (n,n) relatedness matrix — or, with
+    eigen=False, the (n,) vector of its eigenvalues with X, Y, W already rotated (lmm.py:164-167).
+    Returns a pandas.DataFrame with columns beta, se_beta, tau, lambda, F_wald, p_wald[, SNPs].
+    """
+    if de:
+        # calculate_de is broken upstream (unpacks 4 of SampleIter's 5-tuple, lmm/lmm.py:499 vs :434)
+        raise NotImplementedError("de=True is broken in the reference (lmm/lmm.py:499) and is not provided")
+    L = _lib.load()
+    Y, X, W, K = np.asarray(Y), np.asarray(X), np.asarray(W), np.asarray(K)
+    nproc = min(int(nproc), X.shape[1])                      # lmm.py:113
+    if Y.dtype != np.float32:
+        Y = Y.astype(np.float32).reshape(-1, 1)              # lmm.py:115-116
+    if W.dtype != np.float32:
+        W = W.astype(np.float32)                             # lmm.py:118-119
+    if X.dtype != np.float32:
+        X = X.astype(np.float32)                             # lmm.py:121-122
+    if Z is not None:
+        K = np.asarray(Z) @ K @ np.asarray(Z).T              # lmm.py:124-125
+    if K.dtype != np.float32:
+        K = K.astype(np.float32)                             # lmm.py:127-128
+    X = np.ascontiguousarray(X)
+    n, p = X.shape
+    c = W.shape[1]
+    if Y.shape[0] != n or W.shape[0] != n:
+        raise ValueError(f"shape mismatch: Y {Y.shape}, X {X.shape}, W {W.shape}")
+    ngpu = _lib.device_count()
+    if ngpu < 1:
+        raise _lib.PgError("no MI355X visible: pygemma_amd has no CPU path")
+    ndev = max(1, min(nproc, ngpu))
+
+    t0 = time.time()
+    U_host = None
+    if eigen:
+        if K.shape != (n, n):
+            raise ValueError(f"K must be ({n},{n}) when eigen=True, got {K.shape}")
+        with _lib.Context(0) as ctx:
+            dK = ctx.to_device(K)
+            dev, dU = ctx.alloc(n * 4), ctx.alloc(n * n * 4)
+            _lib.check(L.pg_syevd_dev(ctx.handle, n, dK.ptr, dev.ptr, dU.ptr, None, None), "pg_syevd_dev")
+            eigenVals = dev.download((n,), np.float32)       # ascending, clamped >= 0, float32 (lmm.py:152-160)
+            assert (eigenVals >= 0).all()                    # lmm.py:162
+            _log(verbose, f"Eigendecomposition computed - {time.time() - t0:.3f} s")
+            t1 = time.time()
+            YW = _rotate_small(ctx, L, n, dU, np.concatenate([Y.reshape(n, -1)[:, :1], W], axis=1))
+            Yr, Wr = YW[:, :1], np.ascontiguousarray(YW[:, 1:])
+            U_host = dU.download((n, n), np.float32) if True else None
+            _log(verbose, f"Left multiplied Y, W by U.T - {time.time() - t1:.3f} s")
+    else:
+        eigenVals = np.maximum(0.0, K).astype(np.float32).reshape(-1)   # lmm.py:166-167
+        if eigenVals.shape[0] != n:
+            raise ValueError(f"with eigen=False K must hold the {n} eigenvalues, got {K.shape}")
+        Yr, Wr = Y.reshape(n, -1)[:, :1], np.ascontiguousarray(W)
+
+    if not disable_checks:
+        # lmm.py:253-256 (the reference tests the rotated arrays; a NaN anywhere in a raw column makes that
+        # whole rotated column NaN, so testing the inputs raises in exactly the same cases)
+        if np.isnan(X).any() or np.isnan(Yr).any() or np.isnan(Wr).any():
+            raise ValueError("NaNs present in data")
+
+    _log(verbose, f"Running {p} SNPs with {n} individuals on {ndev} GPU(s)...")
+    out = {"beta": np.empty(p, np.float32), "se_beta": np.empty(p, np.float32), "tau": np.empty(p, np.float32),
+           "lambda": np.empty(p, np.float64), "F_wald": np.empty(p, np.float64), "p_wald": np.empty(p, np.float64)}
+    errs, threads = [], []
+    t2 = time.time()
+    yr1 = np.ascontiguousarray(Yr.reshape(-1), np.float32)
+    for dev_id, (a, b) in enumerate(SampleIter(p, ndev)):
+        th = threading.Thread(target=_run_block, args=(dev_id, a, b, n, c, eigenVals, Wr, yr1, X, U_host, grid, eigen,
+                                                       out, errs, verbose))
+        th.start()
+        threads.append(th)
+    for th in threads:
+        th.join()
+    if errs:
+        raise errs[0]
+    _log(verbose, f"Finished testing {p} SNPs in {time.time() - t2:.3f} s")
+    results_df = pd.DataFrame(out, columns=["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"])   # lmm.py:403
+    if snps is not None:
+        results_df["SNPs"] = snps                                                                    # lmm.py:408-409
+    return results_df

@@ -65,7 +65,7 @@ def rotate(U, X, ctx=None, ldx=None):
         ldx = ldx or (n + 63) // 64 * 64
         dU, dX = ctx.to_device(U), ctx.to_device(X)
         dXr = ctx.alloc(p * ldx * 4)
-        _lib.check(L.pg_rotate_dev(ctx.handle, n, p, dU.ptr, dX.ptr, dXr.ptr, ldx), "pg_rotate_dev")
+        _lib.check(L.pg_rotate_dev(ctx.handle, n, p, dU.ptr, n, dX.ptr, p, dXr.ptr, ldx), "pg_rotate_dev")
         ctx.sync()
         out = dXr.download((p, ldx), np.float32)
         for b in (dU, dX, dXr):

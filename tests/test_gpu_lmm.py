@@ -1,0 +1,78 @@
+"""GPU tests of the drop-in entry point lmm.pygemma (through the C ABI)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a.view(np.uint64)
+
+
+@pytest.mark.parametrize("name", ["panel_signal_n400_c5", "panel_weak_n300_c3", "mouse_hs1940_synthG"])
+@pytest.mark.parametrize("grid", [False, True])
+def test_pygemma_eigen_false_matches_reference_dataframe(name, grid):
+    """Tier A through the public API: schema, dtypes and all six columns vs the reference's own DataFrame."""
+    from pygemma import lmm
+    z = np.load(os.path.join(G, name + ".npz"))
+    p = z["X"].shape[1]
+    snps = [f"rs{i}" for i in range(p)]
+    df = lmm.pygemma(z["Y"], z["X"], z["W"], z["d"], snps=snps, grid=grid, eigen=False, nproc=1)
+    assert list(df.columns) == ["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald", "SNPs"]
+    assert [str(t) for t in df.dtypes] == ["float32", "float32", "float32", "float64", "float64", "float64", "object"]
+    assert list(df["SNPs"]) == snps and len(df) == p
+    tag = "grid" if grid else "brent"
+    rowbad = np.zeros(p, bool)
+    for col in ["beta", "se_beta", "tau", "lambda", "F_wald"]:
+        rowbad |= bits(df[col].to_numpy()) != bits(z[f"{tag}_{col}"])
+    assert rowbad.mean() <= 0.01
+    np.testing.assert_allclose(df["p_wald"].to_numpy(), z[f"{tag}_p_wald"], rtol=1e-8)
+
+
+def test_pygemma_float64_inputs_and_no_snps_column():
+    from pygemma import lmm
+    z = np.load(os.path.join(G, "panel_signal_n257_c1.npz"))
+    df = lmm.pygemma(z["Y"].astype(np.float64), z["X"].astype(np.float64), z["W"].astype(np.float64), z["d"].astype(np.float64),
+                     eigen=False)
+    assert list(df.columns) == ["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"]
+    assert (bits(df["beta"].to_numpy()) == bits(z["brent_beta"])).all()
+
+
+def test_pygemma_nan_check_raises_only_when_enabled():
+    from pygemma import lmm
+    z = np.load(os.path.join(G, "panel_signal_n257_c1.npz"))
+    X = z["X"].copy(); X[3, 5] = np.nan
+    with pytest.raises(ValueError, match="NaNs present in data"):
+        lmm.pygemma(z["Y"], X, z["W"], z["d"], eigen=False, disable_checks=False)
+    df = lmm.pygemma(z["Y"], X, z["W"], z["d"], eigen=False)      # default: NaN row comes back, nothing raised
+    assert np.isnan(df["beta"].to_numpy()[5]) and np.isfinite(df["beta"].to_numpy()[4])
+
+
+@pytest.mark.parametrize("grid", [False, True])
+def test_pygemma_full_pipeline_tier_c(grid):
+    """Tier C (eigen=True): build and reference are each compared with an fp64 'truth' pipeline (host dsyevd +
+    fp64 rotation, same lambda rule); the build must not be further from the truth than the reference's own
+    float32 pipeline is, and p-values agree with the reference within 1e-3 on >= 99 % of SNPs."""
+    from oracle import oracle as O
+    from pygemma import lmm
+    z = np.load(os.path.join(G, "eigen_true_n300.npz"))
+    Y, X, W, K = z["Y"], z["X"], z["W"], z["K"]
+    n, p = X.shape
+    df = lmm.pygemma(Y, X, W, K, grid=grid, eigen=True, nproc=1)
+    K64 = np.tril(K.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
+    d, U = np.linalg.eigh(K64)
+    rot = lambda A: (U.T @ A.astype(np.float64)).astype(np.float32)
+    truth = O.calculate(np.maximum(d, 0).astype(np.float32), rot(Y), rot(W), rot(X), grid=grid, order=0, nthreads=4)
+    tag = "grid_" if grid else "brent_"
+    for col in ["beta", "se_beta", "p_wald"]:
+        t = truth[col].astype(np.float64)
+        eb = np.abs(df[col].to_numpy().astype(np.float64) - t) / np.abs(t)
+        er = np.abs(z[tag + col].astype(np.float64) - t) / np.abs(t)
+        assert np.median(eb) <= max(1.5 * np.median(er), 5e-7), (col, np.median(eb), np.median(er))
+        assert np.quantile(eb, 0.99) <= max(2.0 * np.quantile(er, 0.99), 5e-6), (col, eb.max(), er.max())
+    relp = np.abs(df["p_wald"].to_numpy() - z[tag + "p_wald"]) / z[tag + "p_wald"]
+    assert (relp <= 1e-3).mean() >= 0.99

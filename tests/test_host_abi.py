@@ -1,0 +1,77 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every symbol include/pygemma_hip.h
+declares (no compute without a GPU), the host logic mirrors the reference's (SampleIter split, casts, error
+behaviour), and the product never reaches for the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "pygemma_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(pg_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pygemma_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    L = _lib.load()
+    decl = _declared_symbols()
+    assert len(decl) >= 20
+    for sym in decl:
+        assert hasattr(L, sym), f"{sym} declared in include/pygemma_hip.h but not exported"
+    assert set(_lib.SYMBOLS) <= set(decl)
+    assert b"gfx950" in L.pg_version()
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from pygemma_amd import _lib, lmm
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(_lib.PgError):
+        _lib.Context(0)
+    rng = np.random.default_rng(0)
+    with pytest.raises(_lib.PgError):
+        lmm.pygemma(rng.standard_normal((20, 1)), rng.standard_normal((20, 4)), np.ones((20, 1)), np.ones(20), eigen=False)
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pygemma_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import oracle|from oracle)", src, flags=re.M), f
+                assert "liboracle" not in src and "pygemma_oracle" not in src, f
+
+
+def test_sampleiter_matches_reference_split():
+    """lmm/lmm.py:427-434: cols_per_proc = ceil(p/nproc), blocks [r*cols, min((r+1)*cols, p))."""
+    from pygemma_amd.lmm import SampleIter
+    for p, nproc in [(10, 3), (12226, 8), (100000, 8), (7, 7), (5, 1), (9, 4)]:
+        blocks = list(SampleIter(p, nproc))
+        cols = int(np.ceil(p / nproc))
+        exp = [(r * cols, min((r + 1) * cols, p)) for r in range(nproc) if r * cols < p]
+        assert blocks == exp
+        assert blocks[0][0] == 0 and blocks[-1][1] == p
+        assert all(b0[1] == b1[0] for b0, b1 in zip(blocks, blocks[1:]))
+
+
+def test_de_mode_raises_like_a_broken_reference_path():
+    from pygemma_amd import lmm
+    with pytest.raises(NotImplementedError):
+        lmm.pygemma(np.zeros((4, 1)), np.zeros((4, 2)), np.ones((4, 1)), np.eye(4), de=True)
+
+
+def test_drop_in_import_path():
+    from pygemma import lmm
+    import inspect
+    sig = inspect.signature(lmm.pygemma)
+    assert list(sig.parameters) == ["Y", "X", "W", "K", "Z", "snps", "verbose", "disable_checks", "de", "grid", "eigen", "nproc"]
+    d = {k: v.default for k, v in sig.parameters.items() if v.default is not inspect._empty}
+    assert d == {"Z": None, "snps": None, "verbose": 0, "disable_checks": True, "de": False, "grid": False, "eigen": True, "nproc": 1}

@@ -10,7 +10,7 @@ U = rng.standard_normal((n, n), dtype=np.float32); X = rng.standard_normal((n, p
 ldx = (n + 63)//64*64
 dU, dX = ctx.to_device(U), ctx.to_device(X); dXr = ctx.alloc(p*ldx*4)
 def run():
-    _lib.check(L.pg_rotate_dev(ctx.handle, n, p, dU.ptr, dX.ptr, dXr.ptr, ldx), "rot"); ctx.sync()
+    _lib.check(L.pg_rotate_dev(ctx.handle, n, p, dU.ptr, n, dX.ptr, p, dXr.ptr, ldx), "rot"); ctx.sync()
 run(); ts=[]
 for _ in range(5):
     t=time.time(); run(); ts.append(time.time()-t)
