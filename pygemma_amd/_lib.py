@@ -1,7 +1,7 @@
 """ctypes binding of libpygemma_hip.so (C ABI: include/pygemma_hip.h).
 
 The MI355X path has NO CPU fallback: if the shared library is missing or no GPU is visible the
-calls raise.  This module never imports anything from oracle/.
+calls raise.  The checker (the CPU oracle) is test infrastructure and is never imported from here.
 """
 import ctypes as C
 import os
