@@ -35,6 +35,29 @@ F32_MFMA_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_
 F64_VALU_PEAK_TF = 78.6    # fp64 vector peak (= fp64 matrix peak on MI355X): 128 FLOP/clk/CU
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/*_summary.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes at this bench's shapes, gfx950 x2 fetch correction); None if absent."""
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))[-1]
+        return json.load(open(f))["pmc"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def host_cores():
+    """CPU threads this process may actually use (affinity and cgroup quota), for the CPU-baseline leg."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
 def log(rank, *a):
     if rank == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -220,10 +243,12 @@ def main():
         "eigh_note": "fp64 Householder tridiagonalisation + divide&conquer + back-transform on device, n=%d, one-time" % n,
         "roofline": {"kernel": "rotate_kernel<4> (fp32 MFMA 32x32x2)", "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12,
                      "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": rot_flops / rot_avg / 1e12 / F32_MFMA_PEAK_TF,
-                     "traffic": None, "avg_launch_ms": rot_avg * 1e3},
+                     "traffic": pmc_traffic("rotate_kernel") if (n, B) == (10000, 16384) else None,
+                     "algorithmic_bytes": 4.0 * n * B + 4.0 * n * n + 4.0 * ldx * B, "avg_launch_ms": rot_avg * 1e3},
         "roofline_assoc": {"kernel": "assoc_kernel<%d> (+setup, p-values; fp64 VALU)" % c, "bound": "mfma",
                            "achieved": assoc_flops_snp * B / assoc_avg / 1e12, "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": assoc_flops_snp * B / assoc_avg / 1e12 / F64_VALU_PEAK_TF, "traffic": None,
+                           "frac": assoc_flops_snp * B / assoc_avg / 1e12 / F64_VALU_PEAK_TF,
+                           "traffic": pmc_traffic("assoc_kernel") if (n, B, c) == (10000, 16384, 5) else None,
                            "avg_launch_ms": assoc_avg * 1e3,
                            "hbm_GBps_algorithmic": (4.0 * n + 36) * B / assoc_avg / 1e9},
         "stage_snps_per_s_per_gpu": {"rotate": B / rot_avg, "assoc": B / assoc_avg},
@@ -239,7 +264,7 @@ def main():
             Uh = dU.download((n, n), np.float32)
             dh = dev.download((n,), np.float32)
             Xs = np.ascontiguousarray(X[:, :S])
-            nthr = O.lib().orc_max_threads()
+            nthr = min(O.lib().orc_max_threads(), host_cores())
             t = time.time()
             Xrs = O.rotate(Uh, Xs, ldx=ldx)
             t_rot = time.time() - t
