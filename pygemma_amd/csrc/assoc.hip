@@ -252,22 +252,57 @@ __device__ __forceinline__ void sweeps(double *P, double *Q, double *R, double t
     o.ld = ld;
 }
 
-// load one packed fixed row (d, w_0..w_{C-1}, y) for element i as 16-byte vectors
-template <int C>
-__device__ __forceinline__ void load_row(const AssocParams &pr, int i, float &d, float (&col)[C + 2])
+// One element's operands: the packed fixed row (d, w_0..w_{C-1}, y) as 16-byte vectors plus x_i.
+// Loads are unconditional (the x address is clamped, rows >= n are zero in the table) so that the
+// next element's loads can be issued before the current element's arithmetic (software prefetch:
+// at one or two waves per SIMD nothing else hides the L2/MALL latency).
+template <int C> struct Elem {
+    static constexpr int S4 = (C + 2 + 3) / 4;
+    float4 row[S4];
+    float x;
+};
+template <int C, bool HASX = true>
+__device__ __forceinline__ void load_elem(const AssocParams &pr, const float *xrow, int i, Elem<C> &e)
 {
-    constexpr int S4 = (C + 2 + 3) / 4;
-    float buf[4 * S4];
     const float4 *src = reinterpret_cast<const float4 *>(pr.fixed + (size_t)i * pr.rowf);
 #pragma unroll
-    for (int k = 0; k < S4; k++) {
-        float4 v = src[k];
-        buf[4 * k] = v.x; buf[4 * k + 1] = v.y; buf[4 * k + 2] = v.z; buf[4 * k + 3] = v.w;
+    for (int k = 0; k < Elem<C>::S4; k++) e.row[k] = src[k];
+    const int ic = i < pr.n ? i : pr.n - 1;
+    e.x = HASX ? xrow[ic] : 0.0f;
+}
+// software pipeline with a ring of PFD register sets: element it+PFD-1 is already in flight while element
+// it is consumed (the waves run at one per SIMD, so nothing else hides the ~1-2k cycle L2-miss latency of the
+// streamed rows).  Ring slots are compile-time indices (no register copies, no scratch).
+constexpr int PFD = 2;
+template <class E, class LoadF, class BodyF>
+__device__ __forceinline__ void pipelined(int niter, LoadF &&ld, BodyF &&body)
+{
+    E buf[PFD];
+#pragma unroll
+    for (int d = 0; d < PFD; d++) ld(buf[d], d < niter ? d : niter - 1);
+    for (int it = 0; it < niter; it += PFD) {
+#pragma unroll
+        for (int d = 0; d < PFD; d++) {
+            if (it + d < niter) body(buf[d], it + d);
+            const int nx = it + d + PFD;
+            ld(buf[d], nx < niter ? nx : niter - 1);
+        }
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void unpack_elem(const AssocParams &pr, const Elem<C> &e, int i, float &d, float (&col)[C + 2])
+{
+    float buf[4 * Elem<C>::S4];
+#pragma unroll
+    for (int k = 0; k < Elem<C>::S4; k++) {
+        buf[4 * k] = e.row[k].x; buf[4 * k + 1] = e.row[k].y; buf[4 * k + 2] = e.row[k].z; buf[4 * k + 3] = e.row[k].w;
     }
     d = buf[0];
 #pragma unroll
     for (int j = 0; j < C; j++) col[j] = buf[1 + j];
-    col[C + 1] = buf[C + 1];  // y; col[C] (= x) is filled by the caller
+    col[C] = (i < pr.n) ? e.x : 0.0f;
+    col[C + 1] = buf[C + 1];
 }
 
 // Level-0 Grams at an arbitrary lambda: all (C+2)(C+3)/2 entries of P, Q [, R], t1 [, t2]; then the sweeps.
@@ -279,11 +314,11 @@ __device__ __forceinline__ void eval_specific(const AssocParams &pr, const float
 #pragma unroll
     for (int k = 0; k < NP; k++) { P[k] = 0.0; Q[k] = 0.0; if (FULL) R[k] = 0.0; }
     double t1 = 0.0, t2 = 0.0;
-    for (int it = 0; it < pr.niter; it++) {
+    pipelined<Elem<C>>(pr.niter, [&](Elem<C> &e, int it) { load_elem<C>(pr, xrow, it * 64 + lane, e); },
+                       [&](const Elem<C> &cur, int it) {
         const int i = it * 64 + lane;
         float d, colf[M];
-        load_row<C>(pr, i, d, colf);
-        colf[C] = (xrow != nullptr && i < pr.n) ? xrow[i] : 0.0f;
+        unpack_elem<C>(pr, cur, i, d, colf);
         const float h = (i < pr.n) ? hinv_f32(lam, d) : 0.0f;
         const double hd = (double)h;
         double col[M], a[M];
@@ -307,7 +342,7 @@ __device__ __forceinline__ void eval_specific(const AssocParams &pr, const float
             }
             t2 = fma(hd, hd, t2);
         }
-    }
+    });
 #pragma unroll
     for (int k = 0; k < NP; k++) { P[k] = bfly(P[k]); Q[k] = bfly(Q[k]); if (FULL) R[k] = bfly(R[k]); }
     t1 = bfly(t1);
@@ -332,8 +367,9 @@ __global__ __launch_bounds__(64) void setup_tabs_kernel(AssocParams pr)
     for (int it = 0; it < pr.niter; it++) {
         const int i = it * 64 + lane;
         float d, colf[M];
-        load_row<C>(pr, i, d, colf);
-        colf[C] = 0.0f;
+        Elem<C> el;
+        load_elem<C, false>(pr, nullptr, i, el);
+        unpack_elem<C>(pr, el, i, d, colf);
         const float h = (i < pr.n) ? hinv_f32(lam, d) : 0.0f;
         pr.htab[(size_t)t * pr.npad + i] = h;
         const double hd = (double)h;
@@ -369,17 +405,22 @@ __device__ __forceinline__ void scan_accumulate(const AssocParams &pr, const flo
     for (int g = 0; g < G; g++)
 #pragma unroll
         for (int k = 0; k < 2 * M; k++) acc[g][k] = 0.0;
-    for (int it = 0; it < pr.niter; it++) {
+    struct SE { Elem<C> e; float h[G]; };
+    pipelined<SE>(pr.niter, [&](SE &q, int it) {
+        const int i = it * 64 + lane;
+        load_elem<C>(pr, xrow, i, q.e);
+#pragma unroll
+        for (int g = 0; g < G; g++) q.h[g] = pr.htab[(size_t)(t0 + g) * pr.npad + i];
+    }, [&](const SE &q, int it) {
         const int i = it * 64 + lane;
         float d, colf[M];
-        load_row<C>(pr, i, d, colf);
-        colf[C] = (i < pr.n) ? xrow[i] : 0.0f;
+        unpack_elem<C>(pr, q.e, i, d, colf);
         double col[M];
 #pragma unroll
         for (int j = 0; j < M; j++) col[j] = (double)colf[j];
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            const double hd = (double)pr.htab[(size_t)(t0 + g) * pr.npad + i];
+            const double hd = (double)q.h[g];
             double a[M];
 #pragma unroll
             for (int j = 0; j < M; j++) a[j] = hd * col[j];
@@ -392,7 +433,7 @@ __device__ __forceinline__ void scan_accumulate(const AssocParams &pr, const flo
             acc[g][C + 1] = fma(a[C + 1], col[C], acc[g][C + 1]);
             acc[g][M + C + 1] = fma(a[C + 1], a[C], acc[g][M + C + 1]);
         }
-    }
+    });
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
@@ -441,7 +482,9 @@ __device__ __forceinline__ double brentq_dev(Fn &&f, double xa, double xb, doubl
 }
 
 template <int C>
-__global__ __launch_bounds__(64 * WPB) void assoc_kernel(AssocParams pr)
+// two waves per SIMD: a lone wave cannot issue fp64 VALU at the pipe's rate (measured 2.3x faster at 2 than at 1;
+// <= 256 VGPRs at c <= 6 with a handful of spills outside the hot loops); larger c keeps one wave and its registers
+__global__ __launch_bounds__(64 * WPB, (C <= 6 ? 2 : 1)) void assoc_kernel(AssocParams pr)
 {
     constexpr int M = Shape<C>::M, NP = Shape<C>::NP;
     extern __shared__ unsigned char smem[];
