@@ -44,28 +44,50 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
     return t;
 }
 
-// column i of A with the pending panel updates applied:  a = A[:,i] - V W[i,:]' - W V[i,:]'
+// Per column i of the panel (ci = i - i0 columns already in it) four launches:
+//   col_kernel      : finish W[ci-1] (needs the global w.v of the previous column), form column i of A with the
+//                     pending panel updates  a = A[:,i] - V W[i,:]' - W V[i,:]'  and partial sums of |a[i+2:]|^2
+//   larfg_kernel    : Householder reflector of a[i+1:] (multi-workgroup; every workgroup re-derives beta/tau)
+//   symv_dots_kernel: y = A[i+1:, i+1:] v (HBM-bound, 16-byte loads, one wavefront per row) and, in extra
+//                     workgroups, the 2*ci panel dot products W[c,:].v, V[c,:].v
+//   w_update_kernel : w = tau (y - V t1 - W t2) and partial sums of w.v
 // P = [V ; W ; V] stacked (3*NB x n), panel column c of V at P[c*n + r], of W at P[(NB+c)*n + r]
-__global__ void panel_col_kernel(int n, int i, int ci, const double *A, const double *P, double *acol)
+__global__ __launch_bounds__(256) void col_kernel(int n, int i, int ci, int nblk_prev, const double *A, double *P, const double *vprev,
+                                                  const double *wtmp, const double *tauvec, const double *wvpart, double *acol, double *normpart)
 {
-    int r = i + blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    double acc = A[(size_t)r * n + i];
-    const double *V = P, *W = P + (size_t)NB * n;
-    for (int c = 0; c < ci; c++) acc -= V[(size_t)c * n + r] * W[(size_t)c * n + i] + W[(size_t)c * n + r] * V[(size_t)c * n + i];
-    acol[r] = acc;
+    __shared__ double sh[4];
+    const int r = i + blockIdx.x * blockDim.x + threadIdx.x;
+    double *V = P, *W = P + (size_t)NB * n;
+    double alpha = 0.0, wi = 0.0;
+    if (ci > 0) {
+        double dot = 0.0;
+        for (int b = 0; b < nblk_prev; b++) dot += wvpart[b];
+        alpha = -0.5 * tauvec[i - 1] * dot;
+        wi = wtmp[i] + alpha * vprev[i];              // W[ci-1][i]
+    }
+    double sq = 0.0;
+    if (r < n) {
+        double acc = A[(size_t)r * n + i];
+        for (int c = 0; c + 1 < ci; c++) acc -= V[(size_t)c * n + r] * W[(size_t)c * n + i] + W[(size_t)c * n + r] * V[(size_t)c * n + i];
+        if (ci > 0) {
+            const int c = ci - 1;
+            const double wr = wtmp[r] + alpha * vprev[r];
+            W[(size_t)c * n + r] = wr;                 // rows <= i-1 of this column stay zero (panel memset)
+            acc -= V[(size_t)c * n + r] * wi + wr * V[(size_t)c * n + i];
+        }
+        acol[r] = acc;
+        if (r >= i + 2) sq = acc * acc;
+    }
+    sq = block_sum(sq, sh);
+    if (threadIdx.x == 0) normpart[blockIdx.x] = sq;
 }
 
-// Householder reflector for acol[i+1:], one workgroup.  v (with v[i+1] = 1, zeros above) goes to panel column
-// ci of V (both copies), to column i of Vall (row-major n x n) and to vcur; d[i], e[i], tau[i] recorded.
-__global__ __launch_bounds__(1024) void larfg_kernel(int n, int i, int ci, const double *acol, double *P, double *Vall,
-                                                      double *vcur, double *dvec, double *evec, double *tauvec)
+// v (v[i+1] = 1, zeros above) -> panel column ci of V (both copies), column i of Vall, vcur; d[i], e[i], tau[i]
+__global__ __launch_bounds__(256) void larfg_kernel(int n, int i, int ci, int nblk_col, const double *acol, const double *normpart,
+                                                    double *P, double *Vall, double *vcur, double *dvec, double *evec, double *tauvec)
 {
-    __shared__ double sh[16];
-    const int tid = threadIdx.x;
-    double ss = 0.0;
-    for (int r = i + 2 + tid; r < n; r += blockDim.x) ss += acol[r] * acol[r];
-    const double xnorm2 = block_sum(ss, sh);
+    double xnorm2 = 0.0;
+    for (int b = 0; b < nblk_col; b++) xnorm2 += normpart[b];
     const double alpha = acol[i + 1];
     double beta, tau, scal;
     if (xnorm2 == 0.0) { beta = alpha; tau = 0.0; scal = 0.0; }
@@ -74,40 +96,47 @@ __global__ __launch_bounds__(1024) void larfg_kernel(int n, int i, int ci, const
         tau = (beta - alpha) / beta;
         scal = 1.0 / (alpha - beta);
     }
-    double *V1 = P + (size_t)ci * n, *V2 = P + (size_t)(2 * NB + ci) * n;
-    for (int r = tid; r < n; r += blockDim.x) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) {
         double v = 0.0;
         if (r == i + 1) v = 1.0;
         else if (r > i + 1) v = acol[r] * scal;
-        V1[r] = v; V2[r] = v; vcur[r] = v;
+        P[(size_t)ci * n + r] = v; P[(size_t)(2 * NB + ci) * n + r] = v; vcur[r] = v;
         Vall[(size_t)r * n + i] = v;
     }
-    if (tid == 0) { dvec[i] = acol[i]; evec[i] = beta; tauvec[i] = tau; }
+    if (r == 0) { dvec[i] = acol[i]; evec[i] = beta; tauvec[i] = tau; }
 }
 
-// y[r] = sum_{c>i} A[r][c] v[c]  for r > i: one wavefront per row, lanes across columns
-__global__ __launch_bounds__(256) void symv_kernel(int n, int i, const double *A, const double *v, double *y)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = i + 1 + blockIdx.x * 4 + wave;
-    if (r >= n) return;
-    const double *row = A + (size_t)r * n;
-    double acc = 0.0;
-    for (int c = i + 1 + lane; c < n; c += 64) acc = fma(row[c], v[c], acc);
-    for (int s = 1; s < 64; s <<= 1) acc += __shfl_xor(acc, s, 64);
-    if (lane == 0) y[r] = acc;
-}
-
-// t[b] = W[b,:] . v (b < ci) ; t[ci + b] = V[b,:] . v
-__global__ __launch_bounds__(256) void panel_dots_kernel(int n, int i, int ci, const double *P, const double *v, double *t)
+__global__ __launch_bounds__(256) void symv_dots_kernel(int n, int i, int ci, int nsymv, const double *A, const double *P, const double *v,
+                                                        double *y, double *t)
 {
     __shared__ double sh[4];
-    const int b = blockIdx.x;
-    const double *src = (b < ci) ? P + (size_t)(NB + b) * n : P + (size_t)(b - ci) * n;
-    double acc = 0.0;
-    for (int r = i + 1 + threadIdx.x; r < n; r += blockDim.x) acc = fma(src[r], v[r], acc);
-    acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) t[b] = acc;
+    if ((int)blockIdx.x < nsymv) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int r = i + 1 + blockIdx.x * 4 + wave;
+        if (r >= n) return;
+        const double *row = A + (size_t)r * n;
+        double acc = 0.0;
+        if ((n & 1) == 0) {
+            // v[c] = 0 for c <= i, so starting one element early (even index) is harmless and keeps 16-byte alignment
+            for (int c = ((i + 1) & ~1) + 2 * lane; c < n; c += 128) {
+                const double2 a = *reinterpret_cast<const double2 *>(row + c), x = *reinterpret_cast<const double2 *>(v + c);
+                acc = fma(a.x, x.x, acc);
+                acc = fma(a.y, x.y, acc);
+            }
+        } else {
+            for (int c = i + 1 + lane; c < n; c += 64) acc = fma(row[c], v[c], acc);
+        }
+        for (int s = 1; s < 64; s <<= 1) acc += __shfl_xor(acc, s, 64);
+        if (lane == 0) y[r] = acc;
+    } else {
+        const int b = blockIdx.x - nsymv;   // t[b] = W[b,:].v (b < ci) ; t[ci + b] = V[b,:].v
+        const double *src = (b < ci) ? P + (size_t)(NB + b) * n : P + (size_t)(b - ci) * n;
+        double acc = 0.0;
+        for (int r = i + 1 + threadIdx.x; r < n; r += blockDim.x) acc = fma(src[r], v[r], acc);
+        acc = block_sum(acc, sh);
+        if (threadIdx.x == 0) t[b] = acc;
+    }
 }
 
 // w = tau * (y - V t1 - W t2) ; partial[block] = sum w.v
@@ -129,7 +158,7 @@ __global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, con
     if (threadIdx.x == 0) partial[blockIdx.x] = wv;
 }
 
-// W[ci,:] = w - (tau/2)(w.v) v
+// W[ci,:] = w - (tau/2)(w.v) v   (last column of a panel; the others are finished by the next col_kernel)
 __global__ __launch_bounds__(256) void w_final_kernel(int n, int i, int ci, int nblk, double *P, const double *v, const double *wtmp,
                                                       const double *tauvec, const double *partial)
 {
@@ -144,6 +173,7 @@ __global__ __launch_bounds__(256) void w_final_kernel(int n, int i, int ci, int 
 struct SytrdWork {
     double *A = nullptr, *P = nullptr, *Vall = nullptr, *acol = nullptr, *vcur = nullptr, *y = nullptr, *t = nullptr,
            *wtmp = nullptr, *partial = nullptr, *d = nullptr, *e = nullptr, *tau = nullptr;
+    // partial: [0, n/256+2) w.v partial sums, [n/256+2, 2(n/256+2)) column-norm partial sums
 };
 
 // Householder tridiagonalisation of the symmetric fp64 matrix A (n x n, full storage, destroyed).
@@ -154,17 +184,20 @@ static int sytrd_device(pg_ctx *ctx, int n, SytrdWork &w)
     for (int i0 = 0; i0 < n - 1; i0 += NB) {
         const int nbc = std::min(NB, n - 1 - i0);
         PG_HIP(hipMemsetAsync(w.P, 0, (size_t)3 * NB * n * sizeof(double), s));
+        int nblk_prev = 0;
+        double *normpart = w.partial + (n / 256 + 2);
         for (int ci = 0; ci < nbc; ci++) {
             const int i = i0 + ci;
-            const int rows = n - i;
-            panel_col_kernel<<<(rows + 255) / 256, 256, 0, s>>>(n, i, ci, w.A, w.P, w.acol);
-            larfg_kernel<<<1, 1024, 0, s>>>(n, i, ci, w.acol, w.P, w.Vall, w.vcur, w.d, w.e, w.tau);
+            const int nblk_col = (n - i + 255) / 256;
+            col_kernel<<<nblk_col, 256, 0, s>>>(n, i, ci, nblk_prev, w.A, w.P, w.vcur, w.wtmp, w.tau, w.partial, w.acol, normpart);
+            larfg_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, i, ci, nblk_col, w.acol, normpart, w.P, w.Vall, w.vcur, w.d, w.e, w.tau);
             const int nt = n - i - 1;
-            symv_kernel<<<(nt + 3) / 4, 256, 0, s>>>(n, i, w.A, w.vcur, w.y);
-            if (ci > 0) panel_dots_kernel<<<2 * ci, 256, 0, s>>>(n, i, ci, w.P, w.vcur, w.t);
+            const int nsymv = (nt + 3) / 4;
+            symv_dots_kernel<<<nsymv + 2 * ci, 256, 0, s>>>(n, i, ci, nsymv, w.A, w.P, w.vcur, w.y, w.t);
             const int nblk = (nt + 255) / 256;
             w_update_kernel<<<nblk, 256, 0, s>>>(n, i, ci, w.P, w.vcur, w.y, w.t, w.tau, w.wtmp, w.partial);
-            w_final_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, i, ci, nblk, w.P, w.vcur, w.wtmp, w.tau, w.partial);
+            nblk_prev = nblk;
+            if (ci == nbc - 1) w_final_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, i, ci, nblk, w.P, w.vcur, w.wtmp, w.tau, w.partial);
         }
         PG_HIP(hipGetLastError());
         const int off = i0 + nbc;
@@ -177,7 +210,8 @@ static int sytrd_device(pg_ctx *ctx, int n, SytrdWork &w)
         }
     }
     // last diagonal entry
-    panel_col_kernel<<<1, 256, 0, s>>>(n, n - 1, 0, w.A, w.P, w.acol);
+    PG_HIP(hipMemsetAsync(w.P, 0, (size_t)3 * NB * n * sizeof(double), s));
+    col_kernel<<<1, 256, 0, s>>>(n, n - 1, 0, 0, w.A, w.P, w.vcur, w.wtmp, w.tau, w.partial, w.acol, w.partial + (n / 256 + 2));
     PG_HIP(hipMemcpyAsync(w.d + (n - 1), w.acol + (n - 1), sizeof(double), hipMemcpyDeviceToDevice, s));
     PG_HIP(hipGetLastError());
     return PG_OK;
@@ -284,13 +318,20 @@ __global__ void permute_cols_kernel(int n, int r0, int nm, int k, const double *
     else Qout[(size_t)(r0 + r) * n + r0 + jj] = v;
 }
 
-// One thread per root of  f(lam) = 1 + rho * sum_i w_i^2 / (dl_i - lam)  (rho > 0, dl strictly increasing).
+// One WAVEFRONT per root of  f(lam) = 1 + rho * sum_i w_i^2 / (dl_i - lam)  (rho > 0, dl strictly increasing);
+// the 64 lanes split every sum over i and butterfly-reduce, so control flow is wave-uniform.
 // Root j lies in (dl_j, dl_{j+1}) (last: (dl_{k-1}, dl_{k-1} + rho*|w|^2]).  The origin is moved to the
 // nearer pole and the iteration runs on the offset tau, so that every difference dl_i - lam_j is obtained
 // as (dl_i - dl_origin) - tau without cancellation.  Rational ("middle way") steps, bracket-safeguarded.
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
 __global__ __launch_bounds__(256) void secular_kernel(int k, const double *dl, const double *w, double rho, double *Dm, double *lam_out)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= k) return;
     const double eps = 1.1102230246251565e-16;
     int org;
@@ -298,13 +339,15 @@ __global__ __launch_bounds__(256) void secular_kernel(int k, const double *dl, c
     const bool last = (j == k - 1);
     if (last) {
         double sw = 0.0;
-        for (int i = 0; i < k; i++) sw += w[i] * w[i];
+        for (int i = lane; i < k; i += 64) sw += w[i] * w[i];
+        sw = wave_sum(sw);
         org = k - 1; lo = 0.0; hi = rho * sw; tau = 0.5 * hi;
         if (k == 1) tau = hi;
     } else {
-        const double gap = dl[j + 1] - dl[j], half = 0.5 * gap;
-        double fm = 1.0;   // f at the midpoint, deltas taken from dl[j]
-        for (int i = 0; i < k; i++) fm += rho * w[i] * w[i] / ((dl[i] - dl[j]) - half);
+        const double dj = dl[j], gap = dl[j + 1] - dj, half = 0.5 * gap;
+        double fm = 0.0;   // f at the midpoint, deltas taken from dl[j]
+        for (int i = lane; i < k; i += 64) fm += rho * w[i] * w[i] / ((dl[i] - dj) - half);
+        fm = 1.0 + wave_sum(fm);
         if (fm >= 0.0) { org = j; lo = 0.0; hi = half; tau = 0.5 * half; }
         else { org = j + 1; lo = -half; hi = 0.0; tau = -0.5 * half; }
         if (fm == 0.0) { lo = hi = tau = half; }
@@ -313,12 +356,13 @@ __global__ __launch_bounds__(256) void secular_kernel(int k, const double *dl, c
     const int jp = last ? k - 1 : j;   // psi: i <= jp, phi: i > jp
     for (int it = 0; it < 400 && lo != hi; it++) {
         double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0, sabs = 0.0;
-        for (int i = 0; i < k; i++) {
+        for (int i = lane; i < k; i += 64) {
             const double del = (dl[i] - dorg) - tau;
             const double t = rho * w[i] * w[i] / del;
             if (i <= jp) { psi += t; dpsi += t / del; } else { phi += t; dphi += t / del; }
             sabs += fabs(t);
         }
+        psi = wave_sum(psi); dpsi = wave_sum(dpsi); phi = wave_sum(phi); dphi = wave_sum(dphi); sabs = wave_sum(sabs);
         const double f = 1.0 + psi + phi;
         if (f == 0.0) break;
         if (f < 0.0) lo = tau; else hi = tau;   // f is increasing on the interval
@@ -353,8 +397,8 @@ __global__ __launch_bounds__(256) void secular_kernel(int k, const double *dl, c
         if (tnew == tau) break;
         tau = tnew;
     }
-    for (int i = 0; i < k; i++) Dm[(size_t)i * k + j] = (dl[i] - dorg) - tau;
-    lam_out[j] = dorg + tau;
+    for (int i = lane; i < k; i += 64) Dm[(size_t)i * k + j] = (dl[i] - dorg) - tau;
+    if (lane == 0) lam_out[j] = dorg + tau;
 }
 
 // zhat_i = sign(w_i) sqrt| Dm[i][i] * prod_{j != i} Dm[i][j] / (dl_i - dl_j) |   (one wavefront per i)
@@ -533,7 +577,7 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
             }
             permute_cols_kernel<<<(unsigned)(((size_t)nm * nm + 255) / 256), 256, 0, st>>>(n, s, nm, k, Qin, wk.ibuf + n + s, wk.Tp, Qout);
             if (k > 0) {
-                secular_kernel<<<(k + 255) / 256, 256, 0, st>>>(k, wk.dl + s, wk.w + s, mp.rho, wk.Um, wk.dnew + s);
+                secular_kernel<<<(k + 3) / 4, 256, 0, st>>>(k, wk.dl + s, wk.w + s, mp.rho, wk.Um, wk.dnew + s);
                 zhat_kernel<<<(k + 3) / 4, 256, 0, st>>>(k, wk.dl + s, wk.w + s, wk.Um, wk.zh);
                 uvec_kernel<<<(k + 255) / 256, 256, 0, st>>>(k, wk.zh, wk.Um);
                 int rc = dgemm(ctx, false, nm, k, k, 1.0, wk.Tp, k, wk.Um, k, 0.0, Qout + (size_t)s * n + s, n);
@@ -618,7 +662,7 @@ extern "C" int pgx_sytrd_dev(pg_ctx *ctx, int64_t n64, const float *K, double *d
     SytrdWork w;
     int rc = PG_OK;
     double **bufs[] = {&w.A, &w.P, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial};
-    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, (size_t)n / 256 + 2};
+    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, 2 * ((size_t)n / 256 + 2)};
     for (int k = 0; k < 8 && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
     w.Vall = Vall; w.d = d; w.e = e; w.tau = tau;
     if (!rc) {
@@ -714,7 +758,7 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
     double *G = nullptr, *T = nullptr, *W = nullptr, *W2 = nullptr, *dev_ev = nullptr;
     int rc = PG_OK;
     double **bufs[] = {&w.A, &w.P, &w.Vall, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial, &w.d, &w.e, &w.tau, &G, &T, &W, &W2, &dev_ev};
-    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, (size_t)n / 256 + 2,
+    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, 2 * ((size_t)n / 256 + 2),
                       (size_t)n, (size_t)n, (size_t)n, (size_t)NB * NB, (size_t)NB * NB, (size_t)NB * n, (size_t)NB * n, (size_t)n};
     const int nbuf = (int)(sizeof(sizes) / sizeof(sizes[0]));
     auto cleanup = [&]() {
