@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void col_kernel(int n, int i, int ci, int nblk
     double sq = 0.0;
     if (r < n) {
         double acc = A[(size_t)r * n + i];
+#pragma unroll 8
         for (int c = 0; c + 1 < ci; c++) acc -= V[(size_t)c * n + r] * W[(size_t)c * n + i] + W[(size_t)c * n + r] * V[(size_t)c * n + i];
         if (ci > 0) {
             const int c = ci - 1;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, con
     if (r < n) {
         double acc = y[r];
         const double *V = P, *W = P + (size_t)NB * n;
+#pragma unroll 8
         for (int c = 0; c < ci; c++) acc -= V[(size_t)c * n + r] * t[c] + W[(size_t)c * n + r] * t[ci + c];
         acc *= tauvec[i];
         wtmp[r] = acc;

@@ -1,0 +1,70 @@
+"""GPU edge cases of the per-SNP operator: every supported covariate count, tiny / ragged n, single SNP, empty block,
+unsupported c, NaN rows — GPU must equal the oracle (kernel summation order) bit-for-bit wherever results are finite."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a.view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pygemma_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n,p,c", [(40, 5, 1), (65, 70, 2), (130, 33, 4), (96, 20, 6), (150, 24, 7), (128, 16, 8), (200, 12, 9),
+                                   (90, 9, 11), (257, 10, 12), (64, 1, 3), (1000, 7, 5)])
+@pytest.mark.parametrize("grid", [False, True])
+def test_all_covariate_counts_and_ragged_shapes(n, p, c, grid, ctx):
+    from oracle import oracle as O
+    from pygemma_amd import ops, synth
+    rp = synth.rotated_panel(n, p, c, seed=n * 31 + c, null=(c % 2 == 0), h2=0.3)
+    got = ops.assoc(rp["d"], rp["W"], rp["Y"], rp["X"], grid=grid, ctx=ctx)
+    orc = O.calculate(rp["d"], rp["Y"], rp["W"], rp["X"], grid=grid, order=1, nthreads=4)
+    for col in ["beta", "se_beta", "tau", "lambda", "F_wald"]:
+        a, b = got[col], orc[col].astype(got[col].dtype)
+        assert (bits(a) == bits(b)).all(), (col, np.nonzero(bits(a) != bits(b))[0][:5])
+    np.testing.assert_allclose(got["p_wald"], orc["p_wald"], rtol=1e-9)
+
+
+def test_empty_block_and_bad_arguments(ctx):
+    import ctypes as C
+    from pygemma_amd import _lib, ops, synth
+    L = _lib.load()
+    rp = synth.rotated_panel(64, 4, 2, seed=3)
+    # p = 0: nothing to do, success
+    z = np.zeros(1, np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    d, W, y = rp["d"], np.ascontiguousarray(rp["W"]), np.ascontiguousarray(rp["Y"].reshape(-1))
+    assert L.pg_assoc(ctx.handle, 64, 2, 0, vp(d), vp(W), vp(y), vp(z), 0, vp(z), vp(z), vp(z), vp(z), vp(z), vp(z), None) == 0
+    # unsupported number of covariates: loud, with a message, no crash
+    with pytest.raises(_lib.PgError, match="covariates not supported"):
+        ops.assoc(rp["d"], np.ones((64, 13), np.float32), rp["Y"], rp["X"], ctx=ctx)
+    # NULL pointer
+    assert L.pg_assoc(ctx.handle, 64, 2, 4, None, vp(W), vp(y), vp(z), 0, vp(z), vp(z), vp(z), vp(z), vp(z), vp(z), None) < 0
+    assert b"NULL" in L.pg_last_error()
+
+
+def test_nan_snp_gives_nan_row_not_an_error(ctx):
+    """lmm/lmm.py:484-493 semantics: non-finite per-SNP results come back as rows, the scan goes on."""
+    from oracle import oracle as O
+    from pygemma_amd import ops, synth
+    rp = synth.rotated_panel(128, 6, 2, seed=9)
+    X = rp["X"].copy()
+    X[:, 2] = np.nan          # a NaN SNP
+    X[:, 4] = 0.0             # a monomorphic (all-zero after centring) SNP
+    got = ops.assoc(rp["d"], rp["W"], rp["Y"], X, ctx=ctx)
+    orc = O.calculate(rp["d"], rp["Y"], rp["W"], X, grid=False, order=1, nthreads=2)
+    assert np.isnan(got["beta"][2]) and np.isnan(orc["beta"][2])
+    ok = [0, 1, 3, 5]
+    assert (bits(got["beta"][ok]) == bits(orc["beta"][ok])).all()
+    for col in ["beta", "se_beta", "tau", "F_wald"]:       # the degenerate SNP: same non-finite pattern and same bits
+        a, b = got[col][4:5], orc[col][4:5].astype(got[col].dtype)
+        assert (np.isnan(a) == np.isnan(b)).all() and (bits(a)[~np.isnan(a)] == bits(b)[~np.isnan(b)]).all(), col
