@@ -176,77 +176,156 @@ __device__ __forceinline__ float d2_f(const AssocParams &pr, float lam, float yP
 template <int C> struct Shape {
     static constexpr int M = C + 2;             // columns of W* = [W | x | y]
     static constexpr int NP = M * (M + 1) / 2;  // lower-triangle entries
+    static constexpr int SLOTS = (NP + 63) / 64;               // Gram entries owned per lane
+    static constexpr int NV0 = NP < 64 ? NP : 64, NV1 = NP > 64 ? NP - 64 : 0;
+    // scan: decade lambdas handled per pass (their 2M x-entries each must fit one 64-value reduce-scatter)
+    static constexpr int G = (64 / (2 * M)) < 1 ? 1 : ((64 / (2 * M)) > 4 ? 4 : (64 / (2 * M)));
+    // powers accumulated per pass over n: fused while the accumulators fit the register budget of 2 waves/SIMD
+    static constexpr bool FUSE_PQ = NP <= 36, FUSE_PQR = NP <= 28;
 };
 __host__ __device__ constexpr int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // r >= c
+__host__ __device__ constexpr int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 __device__ __forceinline__ double dmaxf(double a, float b) { return ((double)b > a) ? (double)b : a; }
 
-// The c_tot sweeps of precompute_mat on register-resident lower triangles (pyx:947-963 / :1007-1036),
-// arithmetic identical to oracle sweeps(order=1).
-template <int M, bool FULL>
-__device__ __forceinline__ void sweeps(double *P, double *Q, double *R, double t1, double t2, EvalOut &o)
+// 64-lane sums of NVP per-lane partials, one value index per lane ("reduce-scatter"): recursive halving with
+// ascending strides 1,2,4,.. — lane l keeps the values whose index agrees with its low bits and adds its
+// partner's partials of them — then plain butterfly steps for the strides >= NVP.  Every value goes through
+// exactly the additions of the xor-butterfly (strides 1..32) the oracle's order=1 mode performs, so the bits
+// are the same, at ~1/6 of the adds and shuffles.  Returns the total of value index (lane % NVP).
+template <int NVP>
+__device__ __forceinline__ double reduce_scatter(double (&v)[NVP], int lane)
 {
-    P[0] = dmaxf(P[0], PG_MINV);
-    double trP = t1, trPP = t2;
-    float ld = 0.0f;
-    if (M - 2 == 0) { o.Pxx_c = (float)P[tri(M - 2, M - 2)]; o.Pyx_c = (float)P[tri(M - 1, M - 2)]; }
+    static_assert(NVP >= 1 && NVP <= 64 && (NVP & (NVP - 1)) == 0, "power of two");
 #pragma unroll
+    for (int s = 1; s < NVP; s <<= 1) {
+        const bool b = (lane & s) != 0;
+#pragma unroll
+        for (int m = 0; m < NVP / (2 * s); m++) {
+            const double keep = b ? v[2 * m + 1] : v[2 * m];
+            const double send = b ? v[2 * m] : v[2 * m + 1];
+            v[m] = keep + __shfl_xor(send, s, 64);
+        }
+    }
+    double x = v[0];
+#pragma unroll
+    for (int s = NVP; s < 64; s <<= 1) x += __shfl_xor(x, s, 64);
+    return x;
+}
+
+// NP per-lane partials (lower-triangle entries) -> one owned entry per lane and slot: slot 0 holds entry
+// (lane % NVP0) of entries [0,64), slot 1 entry 64 + (lane % NVP1).
+template <int C>
+__device__ __forceinline__ void scatter_entries(const double (&acc)[Shape<C>::NP], int lane, double (&out)[Shape<C>::SLOTS])
+{
+    constexpr int NV0 = Shape<C>::NV0, NV1 = Shape<C>::NV1, NVP0 = next_pow2(NV0);
+    {
+        double t[NVP0];
+#pragma unroll
+        for (int k = 0; k < NVP0; k++) t[k] = (k < NV0) ? acc[k] : 0.0;
+        out[0] = reduce_scatter<NVP0>(t, lane);
+    }
+    if constexpr (NV1 > 0) {
+        constexpr int NVP1 = next_pow2(NV1);
+        double t[NVP1];
+#pragma unroll
+        for (int k = 0; k < NVP1; k++) t[k] = (k < NV1) ? acc[64 + k] : 0.0;
+        out[1] = reduce_scatter<NVP1>(t, lane);
+    }
+}
+
+// which Gram entries a lane owns
+template <int C> struct Own {
+    int e[Shape<C>::SLOTS], r[Shape<C>::SLOTS], c[Shape<C>::SLOTS];
+    bool valid[Shape<C>::SLOTS];
+    __device__ __forceinline__ void init(int lane)
+    {
+        constexpr int NP = Shape<C>::NP, NV0 = Shape<C>::NV0, NV1 = Shape<C>::NV1;
+#pragma unroll
+        for (int sl = 0; sl < Shape<C>::SLOTS; sl++) {
+            const int idx = (sl == 0) ? (lane % next_pow2(NV0)) : 64 + (lane % next_pow2(NV1 > 0 ? NV1 : 1));
+            valid[sl] = (sl == 0) ? (idx < NV0) : (idx < NP);
+            e[sl] = valid[sl] ? idx : 0;
+            int rr = 0;
+            while ((rr + 1) * (rr + 2) / 2 <= e[sl]) rr++;
+            r[sl] = rr; c[sl] = e[sl] - rr * (rr + 1) / 2;
+        }
+    }
+};
+
+// value of Gram entry `es` (per-lane index) / `eq` (wave-uniform index) from its owning lane
+template <int SLOTS>
+__device__ __forceinline__ double gather(const double (&X)[SLOTS], int es)
+{
+    double v = __shfl(X[0], es & 63, 64);
+    if constexpr (SLOTS > 1) { const double w = __shfl(X[1], (es - 64) & 63, 64); v = (es < 64) ? v : w; }
+    return v;
+}
+
+// The c_tot sweeps of precompute_mat (pyx:947-963 / :1007-1036) with the Gram entries spread over the lanes:
+// every lane updates the entry (r,c) it owns, fetching the pivot-column operands from their owners; arithmetic per
+// entry identical to oracle sweeps(order=1).  Scalars (traces, pivots) are wave-uniform.
+template <int C, bool FULL>
+__device__ __forceinline__ void lane_sweeps(double (&P)[Shape<C>::SLOTS], double (&Q)[Shape<C>::SLOTS], double (&R)[Shape<C>::SLOTS],
+                                            const Own<C> &own, double t1, double t2, int lane, EvalOut &o)
+{
+    constexpr int M = Shape<C>::M, NP = Shape<C>::NP, SLOTS = Shape<C>::SLOTS;
+    if (own.valid[0] && own.e[0] == 0) P[0] = dmaxf(P[0], PG_MINV);
+    double trP = t1, trPP = t2, apiv = 1.0;
     for (int i = 1; i < M; i++) {
-        const int q = i - 1;
-        const double a = P[tri(q, q)], b = Q[tri(q, q)];
+        const int q = i - 1, eqq = tri(q, q);
+        const double a = gather<SLOTS>(P, eqq), b = gather<SLOTS>(Q, eqq);
+        const double e = FULL ? gather<SLOTS>(R, eqq) : 0.0;
+        if (lane == q) apiv = a;
+        double ur[SLOTS], uc[SLOTS], vr[SLOTS], vc[SLOTS], wr[SLOTS], wc[SLOTS];
+        bool act[SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; sl++) {
+            act[sl] = own.valid[sl] && own.c[sl] >= i;       // r >= c >= i
+            const int er = act[sl] ? tri(own.r[sl], q) : 0, ec = act[sl] ? tri(own.c[sl], q) : 0;
+            ur[sl] = gather<SLOTS>(P, er); uc[sl] = gather<SLOTS>(P, ec);
+            vr[sl] = gather<SLOTS>(Q, er); vc[sl] = gather<SLOTS>(Q, ec);
+            if (FULL) { wr[sl] = gather<SLOTS>(R, er); wc[sl] = gather<SLOTS>(R, ec); }
+        }
+        const double a2 = a * a, ia = -1.0 / a, ba2 = b / a2;
         if (FULL) {
-            const double e = R[tri(q, q)];
-            double ba = b / a;
+            const double ba = b / a;
             trPP = (trPP + ba * ba) - 2 * (e / a);
-            double a2 = a * a, a3 = a2 * a, b2 = b * b;
-            double cR = (e / a2) - (b2 / a3);
-            double ia = -1.0 / a, ba2 = b / a2;
+            const double a3 = a2 * a, b2 = b * b;
+            const double cR = (e / a2) - (b2 / a3);
 #pragma unroll
-            for (int r = i; r < M; r++)
-#pragma unroll
-                for (int c = i; c <= r; c++) {
-                    double ur = P[tri(r, q)], uc = P[tri(c, q)], vr = Q[tri(r, q)], vc = Q[tri(c, q)];
-                    double wr = R[tri(r, q)], wc = R[tri(c, q)];
-                    double s1 = fma(cR * uc, ur, R[tri(r, c)]);
-                    double s2 = fma(ia * uc, wr, 0.0); s2 = fma(ia * wc, ur, s2);
-                    double s3 = fma(ia * vc, vr, 0.0);
-                    double s4 = fma(ba2 * uc, vr, 0.0); s4 = fma(ba2 * vc, ur, s4);
-                    R[tri(r, c)] = ((s1 + s2) + s3) + s4;
+            for (int sl = 0; sl < SLOTS; sl++)
+                if (act[sl]) {
+                    double s1 = fma(cR * uc[sl], ur[sl], R[sl]);
+                    double s2 = fma(ia * uc[sl], wr[sl], 0.0); s2 = fma(ia * wc[sl], ur[sl], s2);
+                    double s3 = fma(ia * vc[sl], vr[sl], 0.0);
+                    double s4 = fma(ba2 * uc[sl], vr[sl], 0.0); s4 = fma(ba2 * vc[sl], ur[sl], s4);
+                    double rn = ((s1 + s2) + s3) + s4;
+                    if (own.r[sl] == i && own.c[sl] == i) rn = dmaxf(rn, PG_MINV);
+                    R[sl] = rn;
                 }
-            R[tri(i, i)] = dmaxf(R[tri(i, i)], PG_MINV);
         }
         trP = trP - b / a;
-        {
-            double a2 = a * a;
-            double al1 = b / a2, ia = -1.0 / a;
 #pragma unroll
-            for (int r = i; r < M; r++)
-#pragma unroll
-                for (int c = i; c <= r; c++) {
-                    double ur = P[tri(r, q)], uc = P[tri(c, q)], vr = Q[tri(r, q)], vc = Q[tri(c, q)];
-                    double s1 = fma(al1 * uc, ur, Q[tri(r, c)]);
-                    double s2 = fma(ia * uc, vr, 0.0); s2 = fma(ia * vc, ur, s2);
-                    Q[tri(r, c)] = s1 + s2;
-                }
-            Q[tri(i, i)] = dmaxf(Q[tri(i, i)], PG_MINV);
-        }
-        ld = (float)((double)ld + log(a));
-        {
-            double ia = -1.0 / a;
-#pragma unroll
-            for (int r = i; r < M; r++)
-#pragma unroll
-                for (int c = i; c <= r; c++) {
-                    double ur = P[tri(r, q)], uc = P[tri(c, q)];
-                    P[tri(r, c)] = fma(ia * uc, ur, P[tri(r, c)]);
-                }
-            P[tri(i, i)] = dmaxf(P[tri(i, i)], PG_MINV);
-        }
-        if (i == M - 2) { o.Pxx_c = (float)P[tri(M - 2, M - 2)]; o.Pyx_c = (float)P[tri(M - 1, M - 2)]; }
+        for (int sl = 0; sl < SLOTS; sl++)
+            if (act[sl]) {
+                double s1 = fma(ba2 * uc[sl], ur[sl], Q[sl]);
+                double s2 = fma(ia * uc[sl], vr[sl], 0.0); s2 = fma(ia * vc[sl], ur[sl], s2);
+                double qn = s1 + s2;
+                double pn = fma(ia * uc[sl], ur[sl], P[sl]);
+                if (own.r[sl] == i && own.c[sl] == i) { qn = dmaxf(qn, PG_MINV); pn = dmaxf(pn, PG_MINV); }
+                Q[sl] = qn; P[sl] = pn;
+            }
+        if (i == M - 2) { o.Pxx_c = (float)gather<SLOTS>(P, tri(M - 2, M - 2)); o.Pyx_c = (float)gather<SLOTS>(P, tri(M - 1, M - 2)); }
     }
-    o.yPy = (float)P[tri(M - 1, M - 1)];
-    o.yPPy = (float)Q[tri(M - 1, M - 1)];
-    o.yPPPy = FULL ? (float)R[tri(M - 1, M - 1)] : 0.0f;
+    // logdet_Wt_H_inv_W (pyx:957/1029): f32 accumulator += log(pivot), pivots in order; the M-1 logs are taken
+    // at once (lane q holds pivot q), the f32 accumulation stays sequential
+    const double lg = log(apiv);
+    float ld = 0.0f;
+    for (int q = 0; q < M - 1; q++) ld = (float)((double)ld + __shfl(lg, q, 64));
+    o.yPy = (float)gather<SLOTS>(P, NP - 1);
+    o.yPPy = (float)gather<SLOTS>(Q, NP - 1);
+    o.yPPPy = FULL ? (float)gather<SLOTS>(R, NP - 1) : 0.0f;
     o.trP = (float)trP;
     o.trPP = FULL ? (float)trPP : 0.0f;
     o.ld = ld;
@@ -254,8 +333,7 @@ __device__ __forceinline__ void sweeps(double *P, double *Q, double *R, double t
 
 // One element's operands: the packed fixed row (d, w_0..w_{C-1}, y) as 16-byte vectors plus x_i.
 // Loads are unconditional (the x address is clamped, rows >= n are zero in the table) so that the
-// next element's loads can be issued before the current element's arithmetic (software prefetch:
-// at one or two waves per SIMD nothing else hides the L2/MALL latency).
+// next element's loads can be issued before the current element's arithmetic.
 template <int C> struct Elem {
     static constexpr int S4 = (C + 2 + 3) / 4;
     float4 row[S4];
@@ -270,9 +348,7 @@ __device__ __forceinline__ void load_elem(const AssocParams &pr, const float *xr
     const int ic = i < pr.n ? i : pr.n - 1;
     e.x = HASX ? xrow[ic] : 0.0f;
 }
-// software pipeline with a ring of PFD register sets: element it+PFD-1 is already in flight while element
-// it is consumed (the waves run at one per SIMD, so nothing else hides the ~1-2k cycle L2-miss latency of the
-// streamed rows).  Ring slots are compile-time indices (no register copies, no scratch).
+// software pipeline with a ring of PFD register sets (compile-time slots: no register copies, no scratch)
 constexpr int PFD = 2;
 template <class E, class LoadF, class BodyF>
 __device__ __forceinline__ void pipelined(int niter, LoadF &&ld, BodyF &&body)
@@ -289,7 +365,6 @@ __device__ __forceinline__ void pipelined(int niter, LoadF &&ld, BodyF &&body)
         }
     }
 }
-
 template <int C>
 __device__ __forceinline__ void unpack_elem(const AssocParams &pr, const Elem<C> &e, int i, float &d, float (&col)[C + 2])
 {
@@ -305,34 +380,41 @@ __device__ __forceinline__ void unpack_elem(const AssocParams &pr, const Elem<C>
     col[C + 1] = buf[C + 1];
 }
 
-// Level-0 Grams at an arbitrary lambda: all (C+2)(C+3)/2 entries of P, Q [, R], t1 [, t2]; then the sweeps.
-template <int C, bool FULL>
-__device__ __forceinline__ void eval_specific(const AssocParams &pr, const float *xrow, float lam, int lane, EvalOut &o)
+// One pass over the n elements accumulating the level-0 Gram powers selected by MASK (1: P = W*'H^-1 W*,
+// 2: Q = W*'H^-2 W*, 4: R = W*'H^-3 W*; t1 rides with P, t2 with R), then the reduce-scatter to the owning lanes.
+template <int C, int MASK, bool HASX>
+__device__ __forceinline__ void gram_pass(const AssocParams &pr, const float *xrow, float lam, int lane, float *htab_out,
+                                          double (&Po)[Shape<C>::SLOTS], double (&Qo)[Shape<C>::SLOTS], double (&Ro)[Shape<C>::SLOTS],
+                                          double &t1, double &t2)
 {
     constexpr int M = Shape<C>::M, NP = Shape<C>::NP;
-    double P[NP], Q[NP], R[FULL ? NP : 1];
+    constexpr bool DP = (MASK & 1) != 0, DQ = (MASK & 2) != 0, DR = (MASK & 4) != 0;
+    double P[DP ? NP : 1], Q[DQ ? NP : 1], R[DR ? NP : 1];
 #pragma unroll
-    for (int k = 0; k < NP; k++) { P[k] = 0.0; Q[k] = 0.0; if (FULL) R[k] = 0.0; }
-    double t1 = 0.0, t2 = 0.0;
-    pipelined<Elem<C>>(pr.niter, [&](Elem<C> &e, int it) { load_elem<C>(pr, xrow, it * 64 + lane, e); },
+    for (int k = 0; k < NP; k++) { if constexpr (DP) P[k] = 0.0; if constexpr (DQ) Q[k] = 0.0; if constexpr (DR) R[k] = 0.0; }
+    double s1 = 0.0, s2 = 0.0;
+    pipelined<Elem<C>>(pr.niter, [&](Elem<C> &e, int it) { load_elem<C, HASX>(pr, xrow, it * 64 + lane, e); },
                        [&](const Elem<C> &cur, int it) {
         const int i = it * 64 + lane;
         float d, colf[M];
         unpack_elem<C>(pr, cur, i, d, colf);
         const float h = (i < pr.n) ? hinv_f32(lam, d) : 0.0f;
+        if (htab_out) htab_out[i] = h;
         const double hd = (double)h;
         double col[M], a[M];
 #pragma unroll
         for (int j = 0; j < M; j++) { col[j] = (double)colf[j]; a[j] = hd * col[j]; }
+        if (DP || DQ) {
 #pragma unroll
-        for (int j = 0; j < M; j++)
+            for (int j = 0; j < M; j++)
 #pragma unroll
-            for (int k = 0; k <= j; k++) {
-                P[tri(j, k)] = fma(a[j], col[k], P[tri(j, k)]);
-                Q[tri(j, k)] = fma(a[j], a[k], Q[tri(j, k)]);
-            }
-        t1 += hd;
-        if (FULL) {
+                for (int k = 0; k <= j; k++) {
+                    if constexpr (DP) P[tri(j, k)] = fma(a[j], col[k], P[tri(j, k)]);
+                    if constexpr (DQ) Q[tri(j, k)] = fma(a[j], a[k], Q[tri(j, k)]);
+                }
+        }
+        if (DP) s1 += hd;
+        if constexpr (DR) {
             const double h2 = hd * hd;
 #pragma unroll
             for (int j = 0; j < M; j++) {
@@ -340,14 +422,33 @@ __device__ __forceinline__ void eval_specific(const AssocParams &pr, const float
 #pragma unroll
                 for (int k = 0; k <= j; k++) R[tri(j, k)] = fma(gj, a[k], R[tri(j, k)]);
             }
-            t2 = fma(hd, hd, t2);
+            s2 = fma(hd, hd, s2);
         }
     });
+    if constexpr (DP) { scatter_entries<C>(P, lane, Po); t1 = bfly(s1); }
+    if constexpr (DQ) scatter_entries<C>(Q, lane, Qo);
+    if constexpr (DR) { scatter_entries<C>(R, lane, Ro); t2 = bfly(s2); }
+}
+
+// Level-0 Grams at an arbitrary lambda, then the sweeps.
+template <int C, bool FULL>
+__device__ __forceinline__ void eval_specific(const AssocParams &pr, const float *xrow, float lam, int lane, const Own<C> &own, EvalOut &o)
+{
+    constexpr int SLOTS = Shape<C>::SLOTS;
+    double P[SLOTS], Q[SLOTS], R[SLOTS], t1 = 0.0, t2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < NP; k++) { P[k] = bfly(P[k]); Q[k] = bfly(Q[k]); if (FULL) R[k] = bfly(R[k]); }
-    t1 = bfly(t1);
-    if (FULL) t2 = bfly(t2);
-    sweeps<M, FULL>(P, Q, R, t1, t2, o);
+    for (int sl = 0; sl < SLOTS; sl++) R[sl] = 0.0;
+    if constexpr (FULL && Shape<C>::FUSE_PQR) {
+        gram_pass<C, 7, true>(pr, xrow, lam, lane, nullptr, P, Q, R, t1, t2);
+    } else if constexpr (Shape<C>::FUSE_PQ) {
+        gram_pass<C, 3, true>(pr, xrow, lam, lane, nullptr, P, Q, R, t1, t2);
+        if (FULL) gram_pass<C, 4, true>(pr, xrow, lam, lane, nullptr, P, Q, R, t1, t2);
+    } else {
+        gram_pass<C, 1, true>(pr, xrow, lam, lane, nullptr, P, Q, R, t1, t2);
+        gram_pass<C, 2, true>(pr, xrow, lam, lane, nullptr, P, Q, R, t1, t2);
+        if (FULL) gram_pass<C, 4, true>(pr, xrow, lam, lane, nullptr, P, Q, R, t1, t2);
+    }
+    lane_sweeps<C, FULL>(P, Q, R, own, t1, t2, lane, o);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -356,61 +457,45 @@ __device__ __forceinline__ void eval_specific(const AssocParams &pr, const float
 template <int C>
 __global__ __launch_bounds__(64) void setup_tabs_kernel(AssocParams pr)
 {
-    constexpr int M = Shape<C>::M, NP = Shape<C>::NP;
+    constexpr int NP = Shape<C>::NP, SLOTS = Shape<C>::SLOTS;
     extern __shared__ float smem_f[];
     const int t = blockIdx.x, lane = threadIdx.x;
     const float lam = pr.lam11[t];
-    double P[NP], Q[NP];
-#pragma unroll
-    for (int k = 0; k < NP; k++) { P[k] = 0.0; Q[k] = 0.0; }
-    double t1 = 0.0;
-    for (int it = 0; it < pr.niter; it++) {
-        const int i = it * 64 + lane;
-        float d, colf[M];
-        Elem<C> el;
-        load_elem<C, false>(pr, nullptr, i, el);
-        unpack_elem<C>(pr, el, i, d, colf);
-        const float h = (i < pr.n) ? hinv_f32(lam, d) : 0.0f;
-        pr.htab[(size_t)t * pr.npad + i] = h;
-        const double hd = (double)h;
-        double col[M], a[M];
-#pragma unroll
-        for (int j = 0; j < M; j++) { col[j] = (double)colf[j]; a[j] = hd * col[j]; }
-#pragma unroll
-        for (int j = 0; j < M; j++)
-#pragma unroll
-            for (int k = 0; k <= j; k++) {
-                P[tri(j, k)] = fma(a[j], col[k], P[tri(j, k)]);
-                Q[tri(j, k)] = fma(a[j], a[k], Q[tri(j, k)]);
-            }
-        t1 += hd;
+    Own<C> own;
+    own.init(lane);
+    double P[SLOTS], Q[SLOTS], R[SLOTS], t1 = 0.0, t2 = 0.0;
+    if constexpr (Shape<C>::FUSE_PQ) {
+        gram_pass<C, 3, false>(pr, nullptr, lam, lane, pr.htab + (size_t)t * pr.npad, P, Q, R, t1, t2);
+    } else {
+        gram_pass<C, 1, false>(pr, nullptr, lam, lane, pr.htab + (size_t)t * pr.npad, P, Q, R, t1, t2);
+        gram_pass<C, 2, false>(pr, nullptr, lam, lane, nullptr, P, Q, R, t1, t2);
     }
 #pragma unroll
-    for (int k = 0; k < NP; k++) {
-        double pv = bfly(P[k]), qv = bfly(Q[k]);
-        if (lane == 0) { pr.fixg[((size_t)t * 2 + 0) * NP + k] = pv; pr.fixg[((size_t)t * 2 + 1) * NP + k] = qv; }
-    }
-    t1 = bfly(t1);
+    for (int sl = 0; sl < SLOTS; sl++)
+        if (own.valid[sl]) {   // replicas write the same value
+            pr.fixg[((size_t)t * 2 + 0) * NP + own.e[sl]] = P[sl];
+            pr.fixg[((size_t)t * 2 + 1) * NP + own.e[sl]] = Q[sl];
+        }
     float ldH = device_logdet_H(pr, lam, lane, smem_f);
     if (lane == 0) { pr.t1tab[t] = t1; pr.ldHtab[t] = ldH; }
 }
 
-// scan accumulation: only the Gram entries that involve x, for G decade lambdas at once
-template <int C, int G>
+// scan accumulation: only the Gram entries that involve x, for GG decade lambdas at once; the totals go to
+// xent[t][2M] in the wave's LDS (entry k <= C: P(x,k); C+1: P(y,x); M+k likewise for Q)
+template <int C, int GG>
 __device__ __forceinline__ void scan_accumulate(const AssocParams &pr, const float *xrow, int t0, int lane, double *xent)
 {
-    constexpr int M = Shape<C>::M;
-    double acc[G][2 * M];
+    constexpr int M = Shape<C>::M, NV = GG * 2 * M, NVP = next_pow2(NV);
+    static_assert(NV <= 64, "scan group too large");
+    double acc[NVP];
 #pragma unroll
-    for (int g = 0; g < G; g++)
-#pragma unroll
-        for (int k = 0; k < 2 * M; k++) acc[g][k] = 0.0;
-    struct SE { Elem<C> e; float h[G]; };
+    for (int k = 0; k < NVP; k++) acc[k] = 0.0;
+    struct SE { Elem<C> e; float h[GG]; };
     pipelined<SE>(pr.niter, [&](SE &q, int it) {
         const int i = it * 64 + lane;
         load_elem<C>(pr, xrow, i, q.e);
 #pragma unroll
-        for (int g = 0; g < G; g++) q.h[g] = pr.htab[(size_t)(t0 + g) * pr.npad + i];
+        for (int g = 0; g < GG; g++) q.h[g] = pr.htab[(size_t)(t0 + g) * pr.npad + i];
     }, [&](const SE &q, int it) {
         const int i = it * 64 + lane;
         float d, colf[M];
@@ -419,7 +504,7 @@ __device__ __forceinline__ void scan_accumulate(const AssocParams &pr, const flo
 #pragma unroll
         for (int j = 0; j < M; j++) col[j] = (double)colf[j];
 #pragma unroll
-        for (int g = 0; g < G; g++) {
+        for (int g = 0; g < GG; g++) {
             const double hd = (double)q.h[g];
             double a[M];
 #pragma unroll
@@ -427,17 +512,33 @@ __device__ __forceinline__ void scan_accumulate(const AssocParams &pr, const flo
             // row x (index C): columns k <= C ; row y (index C+1): column x
 #pragma unroll
             for (int k = 0; k <= C; k++) {
-                acc[g][k] = fma(a[C], col[k], acc[g][k]);
-                acc[g][M + k] = fma(a[C], a[k], acc[g][M + k]);
+                acc[g * 2 * M + k] = fma(a[C], col[k], acc[g * 2 * M + k]);
+                acc[g * 2 * M + M + k] = fma(a[C], a[k], acc[g * 2 * M + M + k]);
             }
-            acc[g][C + 1] = fma(a[C + 1], col[C], acc[g][C + 1]);
-            acc[g][M + C + 1] = fma(a[C + 1], a[C], acc[g][M + C + 1]);
+            acc[g * 2 * M + C + 1] = fma(a[C + 1], col[C], acc[g * 2 * M + C + 1]);
+            acc[g * 2 * M + M + C + 1] = fma(a[C + 1], a[C], acc[g * 2 * M + M + C + 1]);
         }
     });
-#pragma unroll
-    for (int g = 0; g < G; g++)
-#pragma unroll
-        for (int k = 0; k < 2 * M; k++) xent[(t0 + g) * 2 * M + k] = bfly(acc[g][k]);  // every lane writes the same value
+    const double tot = reduce_scatter<NVP>(acc, lane);
+    const int idx = lane % NVP;
+    if (idx < NV && lane < NVP) xent[t0 * 2 * M + idx] = tot;
+}
+template <int C, int T0>
+__device__ __forceinline__ void scan_all(const AssocParams &pr, const float *xrow, int lane, double *xent)
+{
+    constexpr int G = Shape<C>::G;
+    if constexpr (T0 < NLAM) {
+        constexpr int GG = (NLAM - T0) < G ? (NLAM - T0) : G;
+        scan_accumulate<C, GG>(pr, xrow, T0, lane, xent);
+        scan_all<C, T0 + GG>(pr, xrow, lane, xent);
+    }
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // scipy.optimize.brentq (scipy/optimize/Zeros/brentq.c), xtol=2e-12, rtol=0.1, maxiter=100 (pyx:176-182).
@@ -484,9 +585,9 @@ __device__ __forceinline__ double brentq_dev(Fn &&f, double xa, double xb, doubl
 template <int C>
 // two waves per SIMD: a lone wave cannot issue fp64 VALU at the pipe's rate (measured 2.3x faster at 2 than at 1;
 // <= 256 VGPRs at c <= 6 with a handful of spills outside the hot loops); larger c keeps one wave and its registers
-__global__ __launch_bounds__(64 * WPB, (C <= 6 ? 2 : 1)) void assoc_kernel(AssocParams pr)
+__global__ __launch_bounds__(64 * WPB, 2) void assoc_kernel(AssocParams pr)
 {
-    constexpr int M = Shape<C>::M, NP = Shape<C>::NP;
+    constexpr int M = Shape<C>::M, NP = Shape<C>::NP, SLOTS = Shape<C>::SLOTS;
     extern __shared__ unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long g = (long long)blockIdx.x * WPB + wave;
@@ -501,26 +602,33 @@ __global__ __launch_bounds__(64 * WPB, (C <= 6 ? 2 : 1)) void assoc_kernel(Assoc
     float *vals = lls + NLAM;
     const float *xrow = pr.xr + (size_t)g * pr.ldx;
 
+    Own<C> own;
+    own.init(lane);
     // ---- decade scan: x-dependent Gram entries at the 11 shared lambdas
-    scan_accumulate<C, 4>(pr, xrow, 0, lane, xent);
-    scan_accumulate<C, 4>(pr, xrow, 4, lane, xent);
-    scan_accumulate<C, 3>(pr, xrow, 8, lane, xent);
+    scan_all<C, 0>(pr, xrow, lane, xent);
+    wave_lds_sync();
     for (int t = 0; t < NLAM; t++) {
-        double P[NP], Q[NP], Rdummy[1];
+        double P[SLOTS], Q[SLOTS], R[SLOTS];
         const double *fp = pr.fixg + ((size_t)t * 2 + 0) * NP, *fq = pr.fixg + ((size_t)t * 2 + 1) * NP;
-#pragma unroll
-        for (int k = 0; k < NP; k++) { P[k] = fp[k]; Q[k] = fq[k]; }
         const double *xe = xent + t * 2 * M;
 #pragma unroll
-        for (int k = 0; k <= C; k++) { P[tri(C, k)] = xe[k]; Q[tri(C, k)] = xe[M + k]; }
-        P[tri(C + 1, C)] = xe[C + 1];
-        Q[tri(C + 1, C)] = xe[M + C + 1];
+        for (int sl = 0; sl < SLOTS; sl++) {
+            const int r = own.r[sl], c = own.c[sl];
+            const bool isx = (r == C) || (r == C + 1 && c == C);
+            const int k = (r == C) ? c : C + 1;
+            P[sl] = isx ? xe[k] : fp[own.e[sl]];
+            Q[sl] = isx ? xe[M + k] : fq[own.e[sl]];
+            R[sl] = 0.0;
+        }
         EvalOut e;
-        sweeps<M, false>(P, Q, Rdummy, pr.t1tab[t], 0.0, e);
-        evs[t] = e;
-        d1s[t] = d1_f(pr, pr.lam11[t], e.yPy, e.yPPy, e.trP);
-        lls[t] = logl_f(pr, e.yPy, pr.ldHtab[t], e.ld);
+        lane_sweeps<C, false>(P, Q, R, own, pr.t1tab[t], 0.0, lane, e);
+        if (lane == 0) {
+            evs[t] = e;
+            d1s[t] = d1_f(pr, pr.lam11[t], e.yPy, e.yPPy, e.trP);
+            lls[t] = logl_f(pr, e.yPy, pr.ldHtab[t], e.ld);
+        }
     }
+    wave_lds_sync();
     // ---- candidate selection (pyx:109-117 / :144-152): start from the two boundaries
     float best_l = lls[0], best_lambda;
     EvalOut best_e;
@@ -539,7 +647,7 @@ __global__ __launch_bounds__(64 * WPB, (C <= 6 ? 2 : 1)) void assoc_kernel(Assoc
                 [&](double x) -> double {
                     EvalOut e;
                     const float lf = (float)x;      // pyx:1631: np.float32_t lam
-                    eval_specific<C, false>(pr, xrow, lf, lane, e);
+                    eval_specific<C, false>(pr, xrow, lf, lane, own, e);
                     n_fast++;
                     return (double)d1_f(pr, lf, e.yPy, e.yPPy, e.trP);
                 },
@@ -550,7 +658,7 @@ __global__ __launch_bounds__(64 * WPB, (C <= 6 ? 2 : 1)) void assoc_kernel(Assoc
                 int iteration = 0;
                 for (;;) {
                     EvalOut e;
-                    eval_specific<C, true>(pr, xrow, lroot, lane, e);
+                    eval_specific<C, true>(pr, xrow, lroot, lane, own, e);
                     n_full++;
                     const float d1 = d1_f(pr, lroot, e.yPy, e.yPPy, e.trP);
                     const float d2 = d2_f(pr, lroot, e.yPy, e.yPPy, e.yPPPy, e.trP, e.trPP);
@@ -570,7 +678,7 @@ __global__ __launch_bounds__(64 * WPB, (C <= 6 ? 2 : 1)) void assoc_kernel(Assoc
                 }
             }
             EvalOut e;
-            eval_specific<C, false>(pr, xrow, lroot, lane, e);   // pyx:186
+            eval_specific<C, false>(pr, xrow, lroot, lane, own, e);   // pyx:186
             n_fast++;
             const float ldH = device_logdet_H(pr, lroot, lane, vals);
             const float ll = logl_f(pr, e.yPy, ldH, e.ld);       // pyx:188
