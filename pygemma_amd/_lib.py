@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpygemma_hip.so")
+LIB_PATH = os.environ.get("PYGEMMA_HIP_LIB") or os.path.join(_HERE, "lib", "libpygemma_hip.so")   # env: A/B builds
 _lib = None
 
 SYMBOLS = [

@@ -27,6 +27,19 @@ namespace pg {
 constexpr int NLAM = 11;  // decade lambdas 10^-5 .. 10^5
 constexpr int WPB = 4;    // wavefronts (= SNPs) per workgroup
 #define PG_MINV 1e-35f    // pygemma_model.pyx:39
+// tuning knobs (overridable with -D for A/B builds)
+#ifndef PG_FUSE_PQ_MAX
+#define PG_FUSE_PQ_MAX 36   // fuse the P and Q powers in one pass while (c+2)(c+3)/2 <= this
+#endif
+#ifndef PG_FUSE_PQR_MAX
+#define PG_FUSE_PQR_MAX 28  // fuse all three powers (Newton evaluations)
+#endif
+#ifndef PG_PFD
+#define PG_PFD 2            // prefetch ring depth
+#endif
+#ifndef PG_WAVES
+#define PG_WAVES 2          // waves per SIMD the register allocation is held to
+#endif
 
 struct AssocParams {
     int n, npad, c, niter, nu, grid, rowf;  // nu = n - (c+1); rowf = floats per fixed row (multiple of 4)
@@ -181,7 +194,7 @@ template <int C> struct Shape {
     // scan: decade lambdas handled per pass (their 2M x-entries each must fit one 64-value reduce-scatter)
     static constexpr int G = (64 / (2 * M)) < 1 ? 1 : ((64 / (2 * M)) > 4 ? 4 : (64 / (2 * M)));
     // powers accumulated per pass over n: fused while the accumulators fit the register budget of 2 waves/SIMD
-    static constexpr bool FUSE_PQ = NP <= 36, FUSE_PQR = NP <= 28;
+    static constexpr bool FUSE_PQ = NP <= PG_FUSE_PQ_MAX, FUSE_PQR = NP <= PG_FUSE_PQR_MAX;
 };
 __host__ __device__ constexpr int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // r >= c
 __host__ __device__ constexpr int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -349,7 +362,7 @@ __device__ __forceinline__ void load_elem(const AssocParams &pr, const float *xr
     e.x = HASX ? xrow[ic] : 0.0f;
 }
 // software pipeline with a ring of PFD register sets (compile-time slots: no register copies, no scratch)
-constexpr int PFD = 2;
+constexpr int PFD = PG_PFD;
 template <class E, class LoadF, class BodyF>
 __device__ __forceinline__ void pipelined(int niter, LoadF &&ld, BodyF &&body)
 {
@@ -585,7 +598,7 @@ __device__ __forceinline__ double brentq_dev(Fn &&f, double xa, double xb, doubl
 template <int C>
 // two waves per SIMD: a lone wave cannot issue fp64 VALU at the pipe's rate (measured 2.3x faster at 2 than at 1;
 // <= 256 VGPRs at c <= 6 with a handful of spills outside the hot loops); larger c keeps one wave and its registers
-__global__ __launch_bounds__(64 * WPB, 2) void assoc_kernel(AssocParams pr)
+__global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams pr)
 {
     constexpr int M = Shape<C>::M, NP = Shape<C>::NP, SLOTS = Shape<C>::SLOTS;
     extern __shared__ unsigned char smem[];
@@ -871,8 +884,12 @@ extern "C" int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const floa
     PG_HIP(hipGetLastError());
     switch (c) {
 #define PG_CASE(CC) case CC: rc = launch_assoc<CC>(ctx, pr); break;
+#ifdef PG_ONLY_C
+        PG_CASE(PG_ONLY_C)
+#else
         PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6)
         PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10) PG_CASE(11) PG_CASE(12)
+#endif
 #undef PG_CASE
         default: rc = PG_ENOTSUP;
     }
