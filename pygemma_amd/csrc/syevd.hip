@@ -55,8 +55,11 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
 __global__ __launch_bounds__(256) void col_kernel(int n, int i, int ci, int nblk_prev, const double *A, double *P, const double *vprev,
                                                   const double *wtmp, const double *tauvec, const double *wvpart, double *acol, double *normpart)
 {
+    // 64 rows per workgroup, the panel columns split 4 ways over the waves (short latency chains, 4x the workgroups)
+    __shared__ double part[4][64];
     __shared__ double sh[4];
-    const int r = i + blockIdx.x * blockDim.x + threadIdx.x;
+    const int rr = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int r = i + blockIdx.x * 64 + rr;
     double *V = P, *W = P + (size_t)NB * n;
     double alpha = 0.0, wi = 0.0;
     if (ci > 0) {
@@ -65,11 +68,16 @@ __global__ __launch_bounds__(256) void col_kernel(int n, int i, int ci, int nblk
         alpha = -0.5 * tauvec[i - 1] * dot;
         wi = wtmp[i] + alpha * vprev[i];              // W[ci-1][i]
     }
-    double sq = 0.0;
+    double acc = 0.0;
     if (r < n) {
-        double acc = A[(size_t)r * n + i];
-#pragma unroll 8
-        for (int c = 0; c + 1 < ci; c++) acc -= V[(size_t)c * n + r] * W[(size_t)c * n + i] + W[(size_t)c * n + r] * V[(size_t)c * n + i];
+#pragma unroll 4
+        for (int c = cg; c + 1 < ci; c += 4) acc -= V[(size_t)c * n + r] * W[(size_t)c * n + i] + W[(size_t)c * n + r] * V[(size_t)c * n + i];
+    }
+    part[cg][rr] = acc;
+    __syncthreads();
+    double sq = 0.0;
+    if (cg == 0 && r < n) {
+        acc = A[(size_t)r * n + i] + (((part[0][rr] + part[1][rr]) + part[2][rr]) + part[3][rr]);
         if (ci > 0) {
             const int c = ci - 1;
             const double wr = wtmp[r] + alpha * vprev[r];
@@ -140,18 +148,25 @@ __global__ __launch_bounds__(256) void symv_dots_kernel(int n, int i, int ci, in
     }
 }
 
-// w = tau * (y - V t1 - W t2) ; partial[block] = sum w.v
+// w = tau * (y - V t1 - W t2) ; partial[block] = sum w.v   (64 rows per workgroup, panel columns split 4 ways)
 __global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, const double *P, const double *v, const double *y,
                                                        const double *t, const double *tauvec, double *wtmp, double *partial)
 {
+    __shared__ double part[4][64];
     __shared__ double sh[4];
-    const int r = i + 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    double wv = 0.0;
+    const int rr = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int r = i + 1 + blockIdx.x * 64 + rr;
+    const double *V = P, *W = P + (size_t)NB * n;
+    double acc = 0.0;
     if (r < n) {
-        double acc = y[r];
-        const double *V = P, *W = P + (size_t)NB * n;
-#pragma unroll 8
-        for (int c = 0; c < ci; c++) acc -= V[(size_t)c * n + r] * t[c] + W[(size_t)c * n + r] * t[ci + c];
+#pragma unroll 4
+        for (int c = cg; c < ci; c += 4) acc -= V[(size_t)c * n + r] * t[c] + W[(size_t)c * n + r] * t[ci + c];
+    }
+    part[cg][rr] = acc;
+    __syncthreads();
+    double wv = 0.0;
+    if (cg == 0 && r < n) {
+        acc = y[r] + (((part[0][rr] + part[1][rr]) + part[2][rr]) + part[3][rr]);
         acc *= tauvec[i];
         wtmp[r] = acc;
         wv = acc * v[r];
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(256) void w_final_kernel(int n, int i, int ci, int 
 struct SytrdWork {
     double *A = nullptr, *P = nullptr, *Vall = nullptr, *acol = nullptr, *vcur = nullptr, *y = nullptr, *t = nullptr,
            *wtmp = nullptr, *partial = nullptr, *d = nullptr, *e = nullptr, *tau = nullptr;
-    // partial: [0, n/256+2) w.v partial sums, [n/256+2, 2(n/256+2)) column-norm partial sums
+    // partial: [0, n/64+2) w.v partial sums, [n/64+2, 2(n/64+2)) column-norm partial sums
 };
 
 // Householder tridiagonalisation of the symmetric fp64 matrix A (n x n, full storage, destroyed).
@@ -187,16 +202,16 @@ static int sytrd_device(pg_ctx *ctx, int n, SytrdWork &w)
         const int nbc = std::min(NB, n - 1 - i0);
         PG_HIP(hipMemsetAsync(w.P, 0, (size_t)3 * NB * n * sizeof(double), s));
         int nblk_prev = 0;
-        double *normpart = w.partial + (n / 256 + 2);
+        double *normpart = w.partial + (n / 64 + 2);
         for (int ci = 0; ci < nbc; ci++) {
             const int i = i0 + ci;
-            const int nblk_col = (n - i + 255) / 256;
+            const int nblk_col = (n - i + 63) / 64;
             col_kernel<<<nblk_col, 256, 0, s>>>(n, i, ci, nblk_prev, w.A, w.P, w.vcur, w.wtmp, w.tau, w.partial, w.acol, normpart);
             larfg_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, i, ci, nblk_col, w.acol, normpart, w.P, w.Vall, w.vcur, w.d, w.e, w.tau);
             const int nt = n - i - 1;
             const int nsymv = (nt + 3) / 4;
             symv_dots_kernel<<<nsymv + 2 * ci, 256, 0, s>>>(n, i, ci, nsymv, w.A, w.P, w.vcur, w.y, w.t);
-            const int nblk = (nt + 255) / 256;
+            const int nblk = (nt + 63) / 64;
             w_update_kernel<<<nblk, 256, 0, s>>>(n, i, ci, w.P, w.vcur, w.y, w.t, w.tau, w.wtmp, w.partial);
             nblk_prev = nblk;
             if (ci == nbc - 1) w_final_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, i, ci, nblk, w.P, w.vcur, w.wtmp, w.tau, w.partial);
@@ -213,7 +228,7 @@ static int sytrd_device(pg_ctx *ctx, int n, SytrdWork &w)
     }
     // last diagonal entry
     PG_HIP(hipMemsetAsync(w.P, 0, (size_t)3 * NB * n * sizeof(double), s));
-    col_kernel<<<1, 256, 0, s>>>(n, n - 1, 0, 0, w.A, w.P, w.vcur, w.wtmp, w.tau, w.partial, w.acol, w.partial + (n / 256 + 2));
+    col_kernel<<<1, 256, 0, s>>>(n, n - 1, 0, 0, w.A, w.P, w.vcur, w.wtmp, w.tau, w.partial, w.acol, w.partial + (n / 64 + 2));
     PG_HIP(hipMemcpyAsync(w.d + (n - 1), w.acol + (n - 1), sizeof(double), hipMemcpyDeviceToDevice, s));
     PG_HIP(hipGetLastError());
     return PG_OK;
@@ -664,7 +679,7 @@ extern "C" int pgx_sytrd_dev(pg_ctx *ctx, int64_t n64, const float *K, double *d
     SytrdWork w;
     int rc = PG_OK;
     double **bufs[] = {&w.A, &w.P, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial};
-    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, 2 * ((size_t)n / 256 + 2)};
+    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, 2 * ((size_t)n / 64 + 2)};
     for (int k = 0; k < 8 && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
     w.Vall = Vall; w.d = d; w.e = e; w.tau = tau;
     if (!rc) {
@@ -760,7 +775,7 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
     double *G = nullptr, *T = nullptr, *W = nullptr, *W2 = nullptr, *dev_ev = nullptr;
     int rc = PG_OK;
     double **bufs[] = {&w.A, &w.P, &w.Vall, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial, &w.d, &w.e, &w.tau, &G, &T, &W, &W2, &dev_ev};
-    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, 2 * ((size_t)n / 256 + 2),
+    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, 2 * ((size_t)n / 64 + 2),
                       (size_t)n, (size_t)n, (size_t)n, (size_t)NB * NB, (size_t)NB * NB, (size_t)NB * n, (size_t)NB * n, (size_t)n};
     const int nbuf = (int)(sizeof(sizes) / sizeof(sizes[0]));
     auto cleanup = [&]() {
