@@ -19,6 +19,7 @@
  */
 #ifndef PYGEMMA_HIP_H
 #define PYGEMMA_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -98,6 +99,19 @@ int pg_transpose_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *X_n_by_p, i
  * fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate in sample order i = 0..n-1 — the reference's precision. */
 int pg_rotate_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU, const float *X_n_by_p, int64_t ldX,
                   float *Xr, int64_t ldx);
+
+/* ---- N4: rotation fast path for GENOTYPE columns (each column of the block takes <= 3 equally spaced
+ * values: hard calls 0/1/2, raw or centred/standardised).  U'x = v0 (U'1) + dx (U'code): the codes are exact in bf16,
+ * U is split once into three bf16 planes, the products are exact in fp32 and accumulate in fp32 on the bf16 MFMA pipe
+ * (same error class as pg_rotate_dev / the reference's sgemm, 5x fewer matrix cycles).
+ *   pg_geno_prep_dev   : once per U -> Uprep (pg_geno_prep_bytes(n) bytes, device)
+ *   pg_rotate_geno_dev : per SNP block; *is_geno = 1 and Xr written (same layout as pg_rotate_dev) when every column
+ *                        qualifies, else *is_geno = 0 and Xr untouched (call pg_rotate_dev).  Synchronises the stream. */
+size_t pg_geno_prep_bytes(int64_t n);
+size_t pg_geno_work_bytes(int64_t n, int64_t p);
+int pg_geno_prep_dev(pg_ctx *ctx, int64_t n, const float *U, int64_t ldU, void *Uprep);
+int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const float *X_n_by_p, int64_t ldX, float *Xr,
+                       int64_t ldx, void *work, int *is_geno);
 
 /* ---- N3: relatedness matrix from standardised genotypes, K = G G' / p_k
  * (experiments/animal_gwas/run_gwas.py:45-55, tests/test_pygemma.py:184-192).  Gt is the SNP-major (p_k x ldg)

@@ -2,7 +2,8 @@
 everything under it running on MI355X through the C ABI (include/pygemma_hip.h):
 
     eigh(K)                     -> pg_syevd_dev   (fp64 Householder + divide & conquer, lmm.py:152/197)
-    U.T @ X, U.T @ Y, U.T @ W   -> pg_rotate_dev  (fp32 MFMA GEMM, lmm.py:243-246)
+    U.T @ X, U.T @ Y, U.T @ W   -> pg_rotate_geno_dev for genotype-valued SNP blocks (bf16x3 MFMA), else
+                                   pg_rotate_dev  (fp32 MFMA GEMM)                      (lmm.py:243-246)
     Pool(nproc).imap(calculate) -> pg_assoc_dev   (wave-per-SNP fused lambda search + Wald test, lmm.py:378-403,461-495)
     stats.f.sf                  -> on device      (lmm.py:482)
 
@@ -12,6 +13,7 @@ tau as float32; lambda, F_wald, p_wald as float64; SNPs as object when `snps` is
 column blocks (lmm.py:427-434); results come back in block order = SNP order.
 There is no CPU fallback: without the HIP library or a GPU this raises.
 """
+import ctypes as C
 import threading
 import time
 
@@ -66,6 +68,10 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
             ldx = (n + 63) // 64 * 64
             dd, dW, dy = ctx.to_device(d), ctx.to_device(Wr), ctx.to_device(yr)
             dU = ctx.to_device(U_host) if eigen else None
+            dprep = dwork = None
+            if eigen:   # genotype fast path of the rotation (<= 3 equally spaced values per column), fp32 MFMA otherwise
+                dprep = ctx.alloc(L.pg_geno_prep_bytes(n))
+                _lib.check(L.pg_geno_prep_dev(ctx.handle, n, dU.ptr, n, dprep.ptr), "pg_geno_prep_dev")
             pb_max = max(256, int(_BATCH_BYTES // (4 * (n + ldx))) // 256 * 256)
             pb_max = min(pb_max, b - a)
             ldX = (pb_max + 3) // 4 * 4
@@ -73,13 +79,19 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
             dXr = ctx.alloc(pb_max * ldx * 4)
             dout = ctx.alloc(pb_max * 16)
             dF = ctx.alloc(pb_max * 16)
+            if eigen:
+                dwork = ctx.alloc(L.pg_geno_work_bytes(n, pb_max))
             p = X.shape[1]
             for s in range(a, b, pb_max):
                 e = min(s + pb_max, b)
                 pb = e - s
                 _lib.check(L.pg_memcpy2d_h2d(ctx.handle, dX.ptr, ldX * 4, X.ctypes.data + 4 * s, p * 4, pb * 4, n), "pg_memcpy2d_h2d")
                 if eigen:
-                    _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dX.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
+                    is_geno = C.c_int(0)
+                    _lib.check(L.pg_rotate_geno_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx, dwork.ptr,
+                                                    C.byref(is_geno)), "pg_rotate_geno_dev")
+                    if not is_geno.value:
+                        _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dX.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
                 else:
                     _lib.check(L.pg_transpose_dev(ctx.handle, n, pb, dX.ptr, ldX, dXr.ptr, ldx), "pg_transpose_dev")
                 _lib.check(L.pg_assoc_dev(ctx.handle, n, c, pb, dd.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, int(grid),

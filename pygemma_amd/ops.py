@@ -103,3 +103,30 @@ def syevd(K, ctx=None, want64=False):
     finally:
         if own:
             ctx.close()
+
+
+def rotate_geno(U, X, ctx=None, ldx=None):
+    """Genotype fast path of X <- U'X (pg_rotate_geno_dev).  Returns (Xr (p, ldx) float32, True) when every column of X
+    takes <= 3 equally spaced values, else (None, False)."""
+    L = _lib.load()
+    own = ctx is None
+    ctx = ctx or _lib.Context(0)
+    try:
+        U, X = _f32(U), _f32(X)
+        n, p = X.shape
+        ldx = ldx or (n + 63) // 64 * 64
+        dU, dX = ctx.to_device(U), ctx.to_device(X)
+        dprep = ctx.alloc(L.pg_geno_prep_bytes(n))
+        dwork = ctx.alloc(L.pg_geno_work_bytes(n, p))
+        dXr = ctx.alloc(p * ldx * 4)
+        _lib.check(L.pg_geno_prep_dev(ctx.handle, n, dU.ptr, n, dprep.ptr), "pg_geno_prep_dev")
+        ok = C.c_int(0)
+        _lib.check(L.pg_rotate_geno_dev(ctx.handle, n, p, dprep.ptr, dX.ptr, p, dXr.ptr, ldx, dwork.ptr, C.byref(ok)), "pg_rotate_geno_dev")
+        ctx.sync()
+        out = dXr.download((p, ldx), np.float32) if ok.value else None
+        for b in (dU, dX, dprep, dwork, dXr):
+            b.free()
+        return out, bool(ok.value)
+    finally:
+        if own:
+            ctx.close()

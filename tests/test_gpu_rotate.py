@@ -30,3 +30,45 @@ def test_rotate_bit_exact_vs_oracle(n, p, ctx):
     scale = np.sqrt(n)
     assert np.abs(got[:, :n] - exact).max() <= 2e-6 * scale * 8
     assert (got[:, n:] == 0).all()
+
+
+def _geno(rng, n, p, standardise):
+    maf = rng.uniform(0.05, 0.5, size=p)
+    G = rng.binomial(2, maf, size=(n, p)).astype(np.float64)
+    if standardise:
+        sd = G.std(axis=0); sd[sd == 0] = 1.0
+        G = (G - G.mean(axis=0)) / sd
+    return G.astype(np.float32)
+
+
+@pytest.mark.parametrize("n,p,std", [(64, 32, True), (257, 130, True), (300, 128, False), (1000, 516, True), (2000, 200, True)])
+def test_rotate_genotype_fast_path(n, p, std, ctx):
+    """bf16x3 genotype path: error vs the fp64 rotation within the fp32-GEMM class (and no worse than the fp32-MFMA path)."""
+    from pygemma_amd import ops
+    rng = np.random.default_rng(n + p)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    U = Q.astype(np.float32)
+    X = _geno(rng, n, p, std)
+    X[:, 0] = X[0, 0]                       # a monomorphic column
+    got, ok = ops.rotate_geno(U, X, ctx=ctx)
+    assert ok
+    exact = (U.astype(np.float64).T @ X.astype(np.float64)).T
+    f32p = ops.rotate(U, X, ctx=ctx)[:, :n]
+    bound = (np.abs(X.astype(np.float64)).T @ np.abs(U.astype(np.float64)))      # sum_i |x_i||u_ik|
+    err_g = np.abs(got[:, :n] - exact) / bound
+    err_f = np.abs(f32p - exact) / bound
+    assert err_g.max() <= 4 * 2.0 ** -24 * np.sqrt(n) and np.median(err_g) <= 2 * max(np.median(err_f), 1e-9)
+    assert (got[:, n:] == 0).all()
+
+
+def test_rotate_genotype_rejects_non_genotype_block(ctx):
+    from pygemma_amd import ops
+    rng = np.random.default_rng(3)
+    n, p = 128, 64
+    U = np.linalg.qr(rng.standard_normal((n, n)))[0].astype(np.float32)
+    X = _geno(rng, n, p, True)
+    X[5, 7] += 0.125                        # a fourth value in one column (an imputed dosage)
+    got, ok = ops.rotate_geno(U, X, ctx=ctx)
+    assert not ok and got is None
+    X = _geno(rng, n, p, True); X[3, 3] = np.nan
+    assert ops.rotate_geno(U, X, ctx=ctx)[1] is False
