@@ -173,29 +173,38 @@ __global__ __launch_bounds__(256, 2) void rotate_geno_kernel(GenoParams gp)
 
     // staging: 128 rows x 128 B per operand per stage = 1024 x 16 B; 256 threads x 4
     const int srow = tid >> 3, schunk = tid & 7;     // rows srow + 32*h, 16-byte chunk schunk
+    // The genotype tile of a K-tile serves all three U planes: it is staged once per K-tile (buffer (kt3/3)&1),
+    // only the U-plane tile changes every stage — a third less LDS-write traffic, which is what bounds this loop.
     uint4 ra[4], rb[4];
     auto gload = [&](int kt3) {
-        const long long ka = (long long)(kt3 / 3) * GBK;          // A: genotype codes of K-tile kt3/3
         const long long kb = (long long)kt3 * GBK;                // B: plane-interleaved U tiles
 #pragma unroll
         for (int h = 0; h < 4; h++) {
-            const long long rowm = m0 + srow + 32 * h, rown = n0 + srow + 32 * h;
-            ra[h] = (rowm < gp.p) ? *reinterpret_cast<const uint4 *>(gp.Gt + rowm * gp.ldk + ka + schunk * 8) : make_uint4(0, 0, 0, 0);
+            const long long rown = n0 + srow + 32 * h;
             rb[h] = (rown < gp.n) ? *reinterpret_cast<const uint4 *>(gp.Up + rown * gp.ldp + kb + schunk * 8) : make_uint4(0, 0, 0, 0);
         }
-    };
-    auto lstore = [&](int buf) {
+        if (kt3 % 3 == 0) {
+            const long long ka = (long long)(kt3 / 3) * GBK;      // A: genotype codes of K-tile kt3/3
 #pragma unroll
-        for (int h = 0; h < 4; h++) {
-            *reinterpret_cast<uint4 *>(&As[buf][(srow + 32 * h) * GROWB + schunk * 16]) = ra[h];
-            *reinterpret_cast<uint4 *>(&Bs[buf][(srow + 32 * h) * GROWB + schunk * 16]) = rb[h];
+            for (int h = 0; h < 4; h++) {
+                const long long rowm = m0 + srow + 32 * h;
+                ra[h] = (rowm < gp.p) ? *reinterpret_cast<const uint4 *>(gp.Gt + rowm * gp.ldk + ka + schunk * 8) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto lstore = [&](int kt3) {
+#pragma unroll
+        for (int h = 0; h < 4; h++) *reinterpret_cast<uint4 *>(&Bs[kt3 & 1][(srow + 32 * h) * GROWB + schunk * 16]) = rb[h];
+        if (kt3 % 3 == 0) {
+#pragma unroll
+            for (int h = 0; h < 4; h++) *reinterpret_cast<uint4 *>(&As[(kt3 / 3) & 1][(srow + 32 * h) * GROWB + schunk * 16]) = ra[h];
         }
     };
     gload(0);
     lstore(0);
     __syncthreads();
     for (int kt = 0; kt < gp.KT3; kt++) {
-        const int buf = kt & 1;
+        const int buf = kt & 1, abuf = (kt / 3) & 1;
         if (kt + 1 < gp.KT3) gload(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 16) {
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void rotate_geno_kernel(GenoParams gp)
             const int koff = (kk + 8 * (lane >> 5)) * 2;
             bf16x8 a[2], bb[2];
 #pragma unroll
-            for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const bf16x8 *>(&As[buf][(wm * 64 + i * 32 + (lane & 31)) * GROWB + koff]);
+            for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const bf16x8 *>(&As[abuf][(wm * 64 + i * 32 + (lane & 31)) * GROWB + koff]);
 #pragma unroll
             for (int j = 0; j < 2; j++) bb[j] = *reinterpret_cast<const bf16x8 *>(&Bs[buf][(wn * 64 + j * 32 + (lane & 31)) * GROWB + koff]);
 #pragma unroll
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void rotate_geno_kernel(GenoParams gp)
 #pragma unroll
                 for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < gp.KT3) lstore(buf ^ 1);
+        if (kt + 1 < gp.KT3) lstore(kt + 1);
         __syncthreads();
     }
     // epilogue: Xr[g][k] = v0_g * (U'1)_k + dx_g * acc   (fp64 combine, one rounding to fp32); pad columns zero
