@@ -305,10 +305,10 @@ def main():
                               order=0, nthreads=nthr, snp_major=True)
             t_as = time.time() - t
             same = float((orc["beta"].view(np.uint32) == beta[:S].view(np.uint32)).mean())
-            rel = float(np.max(np.abs(orc["beta"].astype(np.float64) - beta[:S]) / np.maximum(np.abs(orc["beta"]), 1e-30)))
+            rel = float(np.max(np.abs(orc["beta"].astype(np.float64) - beta[:S]) / orc["se_beta"].astype(np.float64)))
             out["cpu_baseline"] = {"value": S / (t_rot + t_as), "unit": "SNPs/s", "cores": int(nthr), "kind": "port",
                                    "sample": f"first {S} SNPs of the step batch: oracle rotate {t_rot:.2f} s + calculate {t_as:.2f} s "
-                                             f"(OpenMP, {nthr} threads); GPU vs oracle beta: {100 * same:.1f}% rows bit-identical, max rel diff {rel:.1e} "
+                                             f"(OpenMP, {nthr} threads); GPU vs oracle beta: {100 * same:.1f}% rows bit-identical, max |dbeta|/se {rel:.1e} "
                                              f"(the oracle rotates with an fp32 fma chain; bit-identity is expected only with --fp32-rotate 1)"}
         except Exception as ex:   # the baseline is a report, not a dependency of the measurement
             out["cpu_baseline"] = {"value": None, "unit": "SNPs/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}

@@ -21,7 +21,14 @@ namespace pg {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int GBM = 128, GBN = 128, GBK = 64, GROWB = GBK * 2 + 16;   // LDS row bytes (padded)
+#ifndef PG_GBK
+#define PG_GBK 64
+#endif
+#ifndef PG_GBLK
+#define PG_GBLK 2
+#endif
+constexpr int GBM = 128, GBN = 128, GBK = PG_GBK, GROWB = GBK * 2 + 16;   // LDS row bytes (padded)
+constexpr int GCH = GBK / 8, GRPP = 256 / GCH, GNH = 128 / GRPP;          // 16-B chunks per row, rows per staging pass, passes
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rn(float f)
 {
@@ -147,7 +154,7 @@ struct GenoParams {
     int tiles_m, tiles_n, KT3;
 };
 
-__global__ __launch_bounds__(256, 2) void rotate_geno_kernel(GenoParams gp)
+__global__ __launch_bounds__(256, PG_GBLK) void rotate_geno_kernel(GenoParams gp)
 {
     __shared__ __attribute__((aligned(16))) unsigned char As[2][GBM * GROWB];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][GBN * GROWB];
@@ -172,32 +179,32 @@ __global__ __launch_bounds__(256, 2) void rotate_geno_kernel(GenoParams gp)
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
     // staging: 128 rows x 128 B per operand per stage = 1024 x 16 B; 256 threads x 4
-    const int srow = tid >> 3, schunk = tid & 7;     // rows srow + 32*h, 16-byte chunk schunk
+    const int srow = tid / GCH, schunk = tid % GCH;     // rows srow + GRPP*h, 16-byte chunk schunk
     // The genotype tile of a K-tile serves all three U planes: it is staged once per K-tile (buffer (kt3/3)&1),
     // only the U-plane tile changes every stage — a third less LDS-write traffic, which is what bounds this loop.
-    uint4 ra[4], rb[4];
+    uint4 ra[GNH], rb[GNH];
     auto gload = [&](int kt3) {
         const long long kb = (long long)kt3 * GBK;                // B: plane-interleaved U tiles
 #pragma unroll
-        for (int h = 0; h < 4; h++) {
-            const long long rown = n0 + srow + 32 * h;
+        for (int h = 0; h < GNH; h++) {
+            const long long rown = n0 + srow + GRPP * h;
             rb[h] = (rown < gp.n) ? *reinterpret_cast<const uint4 *>(gp.Up + rown * gp.ldp + kb + schunk * 8) : make_uint4(0, 0, 0, 0);
         }
         if (kt3 % 3 == 0) {
             const long long ka = (long long)(kt3 / 3) * GBK;      // A: genotype codes of K-tile kt3/3
 #pragma unroll
-            for (int h = 0; h < 4; h++) {
-                const long long rowm = m0 + srow + 32 * h;
+            for (int h = 0; h < GNH; h++) {
+                const long long rowm = m0 + srow + GRPP * h;
                 ra[h] = (rowm < gp.p) ? *reinterpret_cast<const uint4 *>(gp.Gt + rowm * gp.ldk + ka + schunk * 8) : make_uint4(0, 0, 0, 0);
             }
         }
     };
     auto lstore = [&](int kt3) {
 #pragma unroll
-        for (int h = 0; h < 4; h++) *reinterpret_cast<uint4 *>(&Bs[kt3 & 1][(srow + 32 * h) * GROWB + schunk * 16]) = rb[h];
+        for (int h = 0; h < GNH; h++) *reinterpret_cast<uint4 *>(&Bs[kt3 & 1][(srow + GRPP * h) * GROWB + schunk * 16]) = rb[h];
         if (kt3 % 3 == 0) {
 #pragma unroll
-            for (int h = 0; h < 4; h++) *reinterpret_cast<uint4 *>(&As[(kt3 / 3) & 1][(srow + 32 * h) * GROWB + schunk * 16]) = ra[h];
+            for (int h = 0; h < GNH; h++) *reinterpret_cast<uint4 *>(&As[(kt3 / 3) & 1][(srow + GRPP * h) * GROWB + schunk * 16]) = ra[h];
         }
     };
     gload(0);
