@@ -148,9 +148,102 @@ __global__ __launch_bounds__(256) void symv_dots_kernel(int n, int i, int ci, in
     }
 }
 
-// w = tau * (y - V t1 - W t2) ; partial[block] = sum w.v   (64 rows per workgroup, panel columns split 4 ways)
-__global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, const double *P, const double *v, const double *y,
-                                                       const double *t, const double *tauvec, double *wtmp, double *partial)
+// ---- symmetric product from the LOWER triangle only (n even): half the HBM bytes of the full-row kernel above.
+// Trailing rows are cut into 64-row blocks I (from s = i+1), columns into 128-column blocks J from the even origin
+// cb = s & ~1 (16-byte aligned double2 loads; the extra column i, if any, meets v[i] = 0).  One wavefront per tile
+// (I, J), J <= (64 I + 63 + s - cb) / 128: lane l owns columns c, c+1 = cb + 128 J + 2l and uses every loaded element
+// twice,  rowacc[r] += A[r][c] v[c] (c <= r)  and  colacc[c] += A[r][c] v[r] (c < r).  The 64 row sums leave through
+// a reduce-scatter into rowpart[J][r], the column sums into colpart[I][c]; w_update_kernel adds the partials in a
+// fixed order (deterministic, no atomics).  Workgroups with blockIdx.x >= nbr compute the panel dot products.
+template <int NVP>
+__device__ __forceinline__ double reduce_scatter_t(double (&v)[NVP], int lane)
+{
+#pragma unroll
+    for (int st = 1; st < NVP; st <<= 1) {
+        const bool b = (lane & st) != 0;
+#pragma unroll
+        for (int m = 0; m < NVP / (2 * st); m++) {
+            const double keep = b ? v[2 * m + 1] : v[2 * m];
+            const double send = b ? v[2 * m] : v[2 * m + 1];
+            v[m] = keep + __shfl_xor(send, st, 64);
+        }
+    }
+    return v[0];
+}
+
+// 32 rows of a tile: row sums (reduce-scattered: lane l and l+32 both end with the sum of row rbase + l%32) and the
+// running column sums.  Two calls per 64-row tile keep the row accumulators at 32 doubles per lane.
+template <bool INTERIOR>
+__device__ __forceinline__ double symv_half(int n, int rbase, int c0, bool cok, const double *Ac, const double *vrow, double vc0, double vc1,
+                                            int lane, double &col0, double &col1)
+{
+    double rowacc[32];
+#pragma unroll
+    for (int bt = 0; bt < 4; bt++) {
+        double2 a[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int r = rbase + bt * 8 + q;
+            a[q] = (INTERIOR || (cok && r < n)) ? *reinterpret_cast<const double2 *>(Ac + (size_t)r * n) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int r = rbase + bt * 8 + q;
+            const double vr = vrow[bt * 8 + q];           // LDS broadcast (zero for rows past the end)
+            double ax = a[q].x, ay = a[q].y;
+            if (!INTERIOR) { if (c0 > r) ax = 0.0; if (c0 + 1 > r) ay = 0.0; }
+            rowacc[bt * 8 + q] = fma(ax, vc0, ay * vc1);
+            if (!INTERIOR) { if (c0 >= r) ax = 0.0; if (c0 + 1 >= r) ay = 0.0; }
+            col0 = fma(ax, vr, col0);
+            col1 = fma(ay, vr, col1);
+        }
+    }
+    double tot = reduce_scatter_t<32>(rowacc, lane);
+    tot += __shfl_xor(tot, 32, 64);
+    return tot;
+}
+
+__global__ __launch_bounds__(256) void symv_sym_kernel(int n, int i, int ci, int nbr, const double *A, const double *P, const double *v,
+                                                       double *rowpart, double *colpart, double *t)
+{
+    __shared__ double sh[4];
+    __shared__ double vrows[64];
+    const int s = i + 1, cb = s & ~1, delta = s - cb;
+    if ((int)blockIdx.x < nbr) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int I = blockIdx.x, J = blockIdx.y * 4 + wave;
+        const int r0 = s + 64 * I;
+        if (threadIdx.x < 64) vrows[threadIdx.x] = (r0 + threadIdx.x < n) ? v[r0 + threadIdx.x] : 0.0;
+        __syncthreads();
+        if (J > (64 * I + 63 + delta) / 128) return;
+        const int c0 = cb + 128 * J + 2 * lane;
+        const bool cok = c0 < n;                       // n even and c0 even: c0 + 1 < n as well
+        const double vc0 = cok ? v[c0] : 0.0, vc1 = cok ? v[c0 + 1] : 0.0;
+        const double *Ac = A + (cok ? c0 : 0);
+        const bool interior = (r0 + 64 <= n) && (cb + 128 * J + 127 < r0);   // every column left of every row, all in range
+        double col0 = 0.0, col1 = 0.0;
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            const double tot = interior ? symv_half<true>(n, r0 + 32 * hf, c0, cok, Ac, vrows + 32 * hf, vc0, vc1, lane, col0, col1)
+                                        : symv_half<false>(n, r0 + 32 * hf, c0, cok, Ac, vrows + 32 * hf, vc0, vc1, lane, col0, col1);
+            const int r = r0 + 32 * hf + lane;
+            if (lane < 32 && r < n) rowpart[(size_t)J * n + r] = tot;
+        }
+        if (cok) { colpart[(size_t)I * n + c0] = col0; colpart[(size_t)I * n + c0 + 1] = col1; }
+    } else if (blockIdx.y == 0) {
+        const int b = blockIdx.x - nbr;   // t[b] = W[b,:].v (b < ci) ; t[ci + b] = V[b,:].v
+        const double *src = (b < ci) ? P + (size_t)(NB + b) * n : P + (size_t)(b - ci) * n;
+        double acc = 0.0;
+        for (int r = i + 1 + threadIdx.x; r < n; r += blockDim.x) acc = fma(src[r], v[r], acc);
+        acc = block_sum(acc, sh);
+        if (threadIdx.x == 0) t[b] = acc;
+    }
+}
+
+template <bool SYM>
+__global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, int nbr, const double *P, const double *v, const double *y,
+                                                       const double *rowpart, const double *colpart, const double *t, const double *tauvec,
+                                                       double *wtmp, double *partial)
 {
     __shared__ double part[4][64];
     __shared__ double sh[4];
@@ -161,12 +254,24 @@ __global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, con
     if (r < n) {
 #pragma unroll 4
         for (int c = cg; c < ci; c += 4) acc -= V[(size_t)c * n + r] * t[c] + W[(size_t)c * n + r] * t[ci + c];
+        if (SYM) {
+            // (A v)_r from the symmetric partials, split over the 4 waves, each in a fixed order
+            const int s = i + 1, cb = s & ~1, delta = s - cb;
+            const int Ir = (r - s) >> 6, nJ = (64 * Ir + 63 + delta) / 128 + 1;
+            double ya = 0.0;
+            for (int J = cg; J < nJ; J += 4) ya += rowpart[(size_t)J * n + r];
+            const int Jc = (r - cb) >> 7;
+            int Imin = (128 * Jc - delta) / 64;
+            if (Jc == 0) Imin = 0;
+            for (int I = Imin + cg; I < nbr; I += 4) ya += colpart[(size_t)I * n + r];
+            acc += ya;
+        }
     }
     part[cg][rr] = acc;
     __syncthreads();
     double wv = 0.0;
     if (cg == 0 && r < n) {
-        acc = y[r] + (((part[0][rr] + part[1][rr]) + part[2][rr]) + part[3][rr]);
+        acc = (SYM ? 0.0 : y[r]) + (((part[0][rr] + part[1][rr]) + part[2][rr]) + part[3][rr]);
         acc *= tauvec[i];
         wtmp[r] = acc;
         wv = acc * v[r];
@@ -189,7 +294,7 @@ __global__ __launch_bounds__(256) void w_final_kernel(int n, int i, int ci, int 
 
 struct SytrdWork {
     double *A = nullptr, *P = nullptr, *Vall = nullptr, *acol = nullptr, *vcur = nullptr, *y = nullptr, *t = nullptr,
-           *wtmp = nullptr, *partial = nullptr, *d = nullptr, *e = nullptr, *tau = nullptr;
+           *wtmp = nullptr, *partial = nullptr, *d = nullptr, *e = nullptr, *tau = nullptr, *rowpart = nullptr, *colpart = nullptr;
     // partial: [0, n/64+2) w.v partial sums, [n/64+2, 2(n/64+2)) column-norm partial sums
 };
 
@@ -209,10 +314,16 @@ static int sytrd_device(pg_ctx *ctx, int n, SytrdWork &w)
             col_kernel<<<nblk_col, 256, 0, s>>>(n, i, ci, nblk_prev, w.A, w.P, w.vcur, w.wtmp, w.tau, w.partial, w.acol, normpart);
             larfg_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, i, ci, nblk_col, w.acol, normpart, w.P, w.Vall, w.vcur, w.d, w.e, w.tau);
             const int nt = n - i - 1;
-            const int nsymv = (nt + 3) / 4;
-            symv_dots_kernel<<<nsymv + 2 * ci, 256, 0, s>>>(n, i, ci, nsymv, w.A, w.P, w.vcur, w.y, w.t);
             const int nblk = (nt + 63) / 64;
-            w_update_kernel<<<nblk, 256, 0, s>>>(n, i, ci, w.P, w.vcur, w.y, w.t, w.tau, w.wtmp, w.partial);
+            if ((n & 1) == 0 && w.rowpart) {
+                const int nbr = nblk, ywaves = (64 * (nbr - 1) + 64) / 128 + 1;
+                symv_sym_kernel<<<dim3(nbr + 2 * ci, (ywaves + 3) / 4), 256, 0, s>>>(n, i, ci, nbr, w.A, w.P, w.vcur, w.rowpart, w.colpart, w.t);
+                w_update_kernel<true><<<nblk, 256, 0, s>>>(n, i, ci, nbr, w.P, w.vcur, w.y, w.rowpart, w.colpart, w.t, w.tau, w.wtmp, w.partial);
+            } else {
+                const int nsymv = (nt + 3) / 4;
+                symv_dots_kernel<<<nsymv + 2 * ci, 256, 0, s>>>(n, i, ci, nsymv, w.A, w.P, w.vcur, w.y, w.t);
+                w_update_kernel<false><<<nblk, 256, 0, s>>>(n, i, ci, nblk, w.P, w.vcur, w.y, w.rowpart, w.colpart, w.t, w.tau, w.wtmp, w.partial);
+            }
             nblk_prev = nblk;
             if (ci == nbc - 1) w_final_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, i, ci, nblk, w.P, w.vcur, w.wtmp, w.tau, w.partial);
         }
@@ -678,16 +789,17 @@ extern "C" int pgx_sytrd_dev(pg_ctx *ctx, int64_t n64, const float *K, double *d
     const int n = (int)n64;
     SytrdWork w;
     int rc = PG_OK;
-    double **bufs[] = {&w.A, &w.P, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial};
-    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, 2 * ((size_t)n / 64 + 2)};
-    for (int k = 0; k < 8 && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
+    double **bufs[] = {&w.A, &w.P, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial, &w.rowpart, &w.colpart};
+    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, 2 * ((size_t)n / 64 + 2),
+                      ((size_t)n / 128 + 2) * n, ((size_t)n / 64 + 2) * n};
+    for (int k = 0; k < 10 && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
     w.Vall = Vall; w.d = d; w.e = e; w.tau = tau;
     if (!rc) {
         sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, ctx->stream>>>(n, K, w.A);
         rc = sytrd_device(ctx, n, w);
     }
     (void)hipStreamSynchronize(ctx->stream);
-    for (int k = 0; k < 8; k++) if (*bufs[k]) (void)hipFree(*bufs[k]);
+    for (int k = 0; k < 10; k++) if (*bufs[k]) (void)hipFree(*bufs[k]);
     return rc;
 }
 
@@ -774,9 +886,11 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
     StedcWork wk;
     double *G = nullptr, *T = nullptr, *W = nullptr, *W2 = nullptr, *dev_ev = nullptr;
     int rc = PG_OK;
-    double **bufs[] = {&w.A, &w.P, &w.Vall, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial, &w.d, &w.e, &w.tau, &G, &T, &W, &W2, &dev_ev};
+    double **bufs[] = {&w.A, &w.P, &w.Vall, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial, &w.d, &w.e, &w.tau, &G, &T, &W, &W2, &dev_ev,
+                       &w.rowpart, &w.colpart};
     size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, 2 * ((size_t)n / 64 + 2),
-                      (size_t)n, (size_t)n, (size_t)n, (size_t)NB * NB, (size_t)NB * NB, (size_t)NB * n, (size_t)NB * n, (size_t)n};
+                      (size_t)n, (size_t)n, (size_t)n, (size_t)NB * NB, (size_t)NB * NB, (size_t)NB * n, (size_t)NB * n, (size_t)n,
+                      ((size_t)n / 128 + 2) * n, ((size_t)n / 64 + 2) * n};
     const int nbuf = (int)(sizeof(sizes) / sizeof(sizes[0]));
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(st);
