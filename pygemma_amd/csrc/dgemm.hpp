@@ -26,6 +26,7 @@ struct DgemmParams {
     double *C;
     double alpha, beta;
     int vecA, vecB;   // operand base and leading dimension allow 16-byte loads
+    int lower;        // 1: C is symmetric and only its lower triangle is needed: tiles strictly above the diagonal are skipped
     int ksplit;       // > 1: blockIdx.y owns a K range and writes a partial MxN slab to ws (summed by splitk_reduce_kernel)
     long long kchunk;
     double *ws;
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
     __shared__ double Bs[2][DBK][DBN + DPAD];
     const int tiles_n = (int)((gp.N + DBN - 1) / DBN);
     const long long m0 = (long long)(blockIdx.x / tiles_n) * DBM, n0 = (long long)(blockIdx.x % tiles_n) * DBN;
+    if (gp.lower && n0 >= m0 + DBM) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -158,10 +160,10 @@ __global__ void splitk_reduce_kernel(long long M, long long N, int ksplit, const
 }
 
 inline int dgemm(pg_ctx *ctx, bool transA, long long M, long long N, long long K, double alpha, const double *A, long long lda,
-                 const double *B, long long ldb, double beta, double *C, long long ldc)
+                 const double *B, long long ldb, double beta, double *C, long long ldc, bool lower_only = false)
 {
     if (M <= 0 || N <= 0) return PG_OK;
-    DgemmParams gp{M, N, K, lda, ldb, ldc, A, B, C, alpha, beta, 0, 0, 1, K, nullptr};
+    DgemmParams gp{M, N, K, lda, ldb, ldc, A, B, C, alpha, beta, 0, 0, lower_only ? 1 : 0, 1, K, nullptr};
     gp.vecA = ((uintptr_t)A % 16 == 0) && (lda % 2 == 0);
     gp.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 2 == 0);
     const long long tiles = ((M + DBM - 1) / DBM) * ((N + DBN - 1) / DBN);

@@ -332,8 +332,9 @@ static int sytrd_device(pg_ctx *ctx, int n, SytrdWork &w)
         const long long nt = n - off;
         if (nt > 0) {
             // A22 -= V W' + W V'   as one TN GEMM with K = 2*NB:  [V;W]' [W;V]
+            // (lower triangle only when the symmetric symv is in use: nothing reads the upper one any more)
             int rc = dgemm(ctx, true, nt, nt, 2 * NB, -1.0, w.P + off, n, w.P + (size_t)NB * n + off, n, 1.0,
-                           w.A + (size_t)off * n + off, n);
+                           w.A + (size_t)off * n + off, n, (n & 1) == 0 && w.rowpart != nullptr);
             if (rc) return rc;
         }
     }
@@ -543,15 +544,21 @@ __global__ __launch_bounds__(256) void zhat_kernel(int k, const double *dl, cons
     if (lane == 0) zh[i] = copysign(sqrt(fabs(prod)), w[i]);
 }
 
-// U[:, j] = (zh_i / Dm[i][j])_i, normalised; in place over Dm (one thread per column: coalesced across j)
+// U[:, j] = (zh_i / Dm[i][j])_i, normalised; in place over Dm.  64 columns per workgroup (coalesced across j), the rows
+// split over the 4 waves, column norms combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void uvec_kernel(int k, const double *zh, double *Dm)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= k) return;
+    __shared__ double part[4][64];
+    const int jj = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jj;
     double ss = 0.0;
-    for (int i = 0; i < k; i++) { double v = zh[i] / Dm[(size_t)i * k + j]; ss += v * v; }
-    const double inv = 1.0 / sqrt(ss);
-    for (int i = 0; i < k; i++) { double v = zh[i] / Dm[(size_t)i * k + j]; Dm[(size_t)i * k + j] = v * inv; }
+    if (j < k)
+        for (int i = rg; i < k; i += 4) { const double v = zh[i] / Dm[(size_t)i * k + j]; ss += v * v; }
+    part[rg][jj] = ss;
+    __syncthreads();
+    if (j >= k) return;
+    const double inv = 1.0 / sqrt(((part[0][jj] + part[1][jj]) + part[2][jj]) + part[3][jj]);
+    for (int i = rg; i < k; i += 4) { const double v = zh[i] / Dm[(size_t)i * k + j]; Dm[(size_t)i * k + j] = v * inv; }
 }
 
 __global__ void copy_block_kernel(int n, int r0, int nm, const double *Qin, double *Qout)
@@ -707,7 +714,7 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
             if (k > 0) {
                 secular_kernel<<<(k + 3) / 4, 256, 0, st>>>(k, wk.dl + s, wk.w + s, mp.rho, wk.Um, wk.dnew + s);
                 zhat_kernel<<<(k + 3) / 4, 256, 0, st>>>(k, wk.dl + s, wk.w + s, wk.Um, wk.zh);
-                uvec_kernel<<<(k + 255) / 256, 256, 0, st>>>(k, wk.zh, wk.Um);
+                uvec_kernel<<<(k + 63) / 64, 256, 0, st>>>(k, wk.zh, wk.Um);
                 int rc = dgemm(ctx, false, nm, k, k, 1.0, wk.Tp, k, wk.Um, k, 0.0, Qout + (size_t)s * n + s, n);
                 if (rc) return rc;
             }
