@@ -18,7 +18,10 @@ namespace pg {
 
 typedef double doublex4 __attribute__((ext_vector_type(4)));
 
-constexpr int DBM = 128, DBN = 128, DBK = 8, DPAD = 16;
+#ifndef PG_DBK
+#define PG_DBK 8
+#endif
+constexpr int DBM = 128, DBN = 128, DBK = PG_DBK, DPAD = 16, DPASS = DBK / 8;   // staging works in passes of 8 k-rows
 
 struct DgemmParams {
     long long M, N, K, lda, ldb, ldc;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
 
     const long long kbeg_ = (gp.ksplit > 1) ? (long long)blockIdx.y * gp.kchunk : 0;
     const long long KEND = (gp.ksplit > 1) ? ((kbeg_ + gp.kchunk < gp.K) ? kbeg_ + gp.kchunk : gp.K) : gp.K;
-    double ra[4], rb[4];
+    double ra[DPASS][4], rb[DPASS][4];
     // interior tiles with 16-byte-aligned operands take two double2 loads per operand; edges go element-wise
     const bool fastB = gp.vecB && (n0 + DBN <= gp.N);
     const bool fastA = gp.vecA && (m0 + DBM <= gp.M);
@@ -61,42 +64,49 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
         const double2 u = *reinterpret_cast<const double2 *>(p), w = *reinterpret_cast<const double2 *>(p + 2);
         r[0] = u.x; r[1] = u.y; r[2] = w.x; r[3] = w.y;
     };
-    auto gload = [&](long long k0) {
-        // B tile: 8 rows (k) x 128 cols: thread -> row tid/32, 4 consecutive cols
-        {
-            const long long kr = k0 + (tid >> 5), col = n0 + (tid & 31) * 4;
-            if (fastB && kr < KEND) load4d(gp.B + kr * gp.ldb + col, rb);
-            else {
+    auto gload = [&](long long kbase) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) rb[q] = (kr < KEND && col + q < gp.N) ? gp.B[kr * gp.ldb + col + q] : 0.0;
+        for (int ps = 0; ps < DPASS; ps++) {
+            const long long k0 = kbase + 8 * ps;
+            // B tile: 8 rows (k) x 128 cols: thread -> row tid/32, 4 consecutive cols
+            {
+                const long long kr = k0 + (tid >> 5), col = n0 + (tid & 31) * 4;
+                if (fastB && kr < KEND) load4d(gp.B + kr * gp.ldb + col, rb[ps]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) rb[ps][q] = (kr < KEND && col + q < gp.N) ? gp.B[kr * gp.ldb + col + q] : 0.0;
+                }
             }
-        }
-        if (TA) {
-            const long long kr = k0 + (tid >> 5), col = m0 + (tid & 31) * 4;
-            if (fastA && kr < KEND) load4d(gp.A + kr * gp.lda + col, ra);
-            else {
+            if (TA) {
+                const long long kr = k0 + (tid >> 5), col = m0 + (tid & 31) * 4;
+                if (fastA && kr < KEND) load4d(gp.A + kr * gp.lda + col, ra[ps]);
+                else {
 #pragma unroll
-                for (int q = 0; q < 4; q++) ra[q] = (kr < KEND && col + q < gp.M) ? gp.A[kr * gp.lda + col + q] : 0.0;
-            }
-        } else {
-            // A tile: 128 rows (m) x 8 (k): thread -> row tid/2, 4 consecutive k
-            const long long row = m0 + (tid >> 1), kc = k0 + (tid & 1) * 4;
-            if (fastA && kc + 3 < KEND) load4d(gp.A + row * gp.lda + kc, ra);
-            else {
+                    for (int q = 0; q < 4; q++) ra[ps][q] = (kr < KEND && col + q < gp.M) ? gp.A[kr * gp.lda + col + q] : 0.0;
+                }
+            } else {
+                // A tile: 128 rows (m) x 8 (k): thread -> row tid/2, 4 consecutive k
+                const long long row = m0 + (tid >> 1), kc = k0 + (tid & 1) * 4;
+                if (fastA && kc + 3 < KEND) load4d(gp.A + row * gp.lda + kc, ra[ps]);
+                else {
 #pragma unroll
-                for (int q = 0; q < 4; q++) ra[q] = (row < gp.M && kc + q < KEND) ? gp.A[row * gp.lda + kc + q] : 0.0;
+                    for (int q = 0; q < 4; q++) ra[ps][q] = (row < gp.M && kc + q < KEND) ? gp.A[row * gp.lda + kc + q] : 0.0;
+                }
             }
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) Bs[buf][tid >> 5][(tid & 31) * 4 + q] = rb[q];
-        if (TA) {
+        for (int ps = 0; ps < DPASS; ps++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) As[buf][tid >> 5][(tid & 31) * 4 + q] = ra[q];
-        } else {
+            for (int q = 0; q < 4; q++) Bs[buf][8 * ps + (tid >> 5)][(tid & 31) * 4 + q] = rb[ps][q];
+            if (TA) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) As[buf][(tid & 1) * 4 + q][tid >> 1] = ra[q];
+                for (int q = 0; q < 4; q++) As[buf][8 * ps + (tid >> 5)][(tid & 31) * 4 + q] = ra[ps][q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) As[buf][8 * ps + (tid & 1) * 4 + q][tid >> 1] = ra[ps][q];
+            }
         }
     };
 
