@@ -224,3 +224,56 @@ if __name__ == "__main__":
         gen_eigen_true()
     if "mouse" in which:
         gen_mouse()
+
+
+def gen_reference_test_matrices():
+    """The reference's own test inputs: generate_test_matrices(n=1000, covars=10, seed=42) (tests/test_pygemma.py:195-212)
+    pushed through the live-path functions of its function list (:258-295) at lam in {1e-3, 5, 400, 1e3, 1e5} (:253).
+    W there ends up holding x TWICE (np.c_[W, x] at :225 and again at :258-): c = 12 covariates, the SNP collinear with
+    one of them — the degenerate case in which the MIN_VAL pivot clamps (pyx:939-961) decide the numbers."""
+    np.random.seed(42)
+    n, covars = 1000, 10
+    K = np.random.uniform(size=(n, n))
+    K = np.abs(np.tril(K) + np.tril(K, -1).T)
+    K = np.dot(K, K.T)
+    eigenVals, U = np.linalg.eig(K)
+    eigenVals = np.maximum(0, eigenVals)
+    W = np.random.rand(n, covars)
+    W = np.c_[W, np.ones(n)]
+    x = np.random.choice([0, 1, 2], size=(n, 1), replace=True)
+    Y = np.random.rand(n, 1).reshape(-1, 1)
+    x, Y, W = x.astype(np.float32), Y.astype(np.float32), W.astype(np.float32)
+    eigenVals, U = np.real(eigenVals).astype(np.float32), np.real(U).astype(np.float32)
+    W = np.c_[W, x]
+    xr = (U.T @ x).reshape(-1)
+    Yr = U.T @ Y
+    Wr = np.ascontiguousarray(U.T @ W)
+    out = {"versions": VERS, "d": eigenVals, "x": xr, "Y": Yr, "W": Wr, "lams": np.array([1e-3, 5.0, 400, 1e3, 1e5], np.float32)}
+    Wx = np.ascontiguousarray(np.c_[Wr, xr])
+    c = Wx.shape[1]
+    m = c + 1
+    msk = defined_mask(m)
+    for li, lam in enumerate([1e-3, 5.0, 400, 1e3, 1e5]):
+        for full in (0, 1):
+            r = quiet(ref.precompute_mat, lam, eigenVals, Wx, Yr, bool(full))
+            key = f"l{li}_f{full}_"
+            out[key + "P3"] = np.where(msk, r["wjt_Pi_wk"], np.nan).astype(np.float32)
+            out[key + "yPy"], out[key + "yPPy"], out[key + "trP"] = r["yt_Pi_y"], r["yt_Pi_Pi_y"], r["tr_Pi"]
+            out[key + "ld"], out[key + "ldH"] = np.float32(r["logdet_Wt_H_inv_W"]), np.float32(r["logdet_H"])
+            if full:
+                out[key + "yPPPy"], out[key + "trPP"] = r["yt_Pi_Pi_Pi_y"], r["tr_Pi_Pi"]
+        b = quiet(ref.calc_beta_vg_ve_restricted_overload, eigenVals, Wr, xr.reshape(-1, 1), np.float32(lam), Yr)
+        out[f"l{li}_beta"] = np.array([b[0], b[2], b[3]], np.float32)
+        out[f"l{li}_d1"] = np.float32(ref.wrapper_likelihood_derivative1_restricted_lambda(np.float32(lam), eigenVals, Yr, Wx))
+        out[f"l{li}_newton"] = np.float32(quiet(ref.newton, lam, eigenVals, Yr, Wx, True))
+    out["calc_lambda_restricted"] = np.float64(quiet(ref.calc_lambda_restricted, eigenVals, Yr, Wx))
+    out["calc_lambda_restricted_grid"] = np.float64(quiet(ref.calc_lambda_restricted, eigenVals, Yr, Wx, grid=True))
+    df = quiet(ref.pygemma, Yr, xr.reshape(-1, 1), Wr, eigenVals, eigen=False, nproc=1)
+    for col in ["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"]:
+        out["df_" + col] = df[col].to_numpy()
+    np.savez_compressed(os.path.join(HERE, "reference_test_matrices.npz"), **out)
+    print("reference_test_matrices.npz: lambda", out["calc_lambda_restricted"], "beta row", [df[c].to_numpy()[0] for c in df.columns])
+
+
+if __name__ == "__main__" and "refmat" in sys.argv[1:]:
+    gen_reference_test_matrices()

@@ -68,3 +68,22 @@ def test_nan_snp_gives_nan_row_not_an_error(ctx):
     for col in ["beta", "se_beta", "tau", "F_wald"]:       # the degenerate SNP: same non-finite pattern and same bits
         a, b = got[col][4:5], orc[col][4:5].astype(got[col].dtype)
         assert (np.isnan(a) == np.isnan(b)).all() and (bits(a)[~np.isnan(a)] == bits(b)[~np.isnan(b)]).all(), col
+
+
+def test_reference_test_matrices_collinear_snp_c12(ctx):
+    """The reference's own test inputs (tests/test_pygemma.py:195-212): c = 12 covariates one of which is the SNP itself.
+    Pivot clamps decide the row; the GPU must still agree bit-for-bit with the oracle in kernel order, select the
+    reference's lambda, and land within the noise band of the reference's (cancellation-dominated) beta."""
+    import os
+    from oracle import oracle as O
+    from pygemma_amd import ops
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_test_matrices.npz"))
+    X = np.ascontiguousarray(np.repeat(z["x"].reshape(-1, 1), 5, axis=1))
+    got = ops.assoc(z["d"], z["W"], z["Y"], X, ctx=ctx)
+    orc = O.calculate(z["d"], z["Y"], z["W"], X, grid=False, order=1, nthreads=2)
+    for col in ["beta", "se_beta", "tau", "lambda", "F_wald"]:
+        a, b = got[col], orc[col].astype(got[col].dtype)
+        assert (bits(a) == bits(b)).all(), col
+    assert got["lambda"][0] == z["df_lambda"][0]
+    assert abs(got["beta"][0] - z["df_beta"][0]) <= 5e-2 * abs(z["df_beta"][0])
+    assert abs(got["tau"][0] - z["df_tau"][0]) <= 1e-4 * abs(z["df_tau"][0])

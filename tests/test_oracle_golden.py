@@ -177,3 +177,38 @@ def test_reference_output_schema_pin():
     # lambda column holds float32-precision values widened to float64 (e.g. 9.999999747378752e-06)
     lam = z["brent_lambda"]
     assert (lam.astype(np.float32).astype(np.float64) == lam).all()
+
+
+def test_reference_own_test_matrices_degenerate_collinear_snp():
+    """The reference's own test inputs (tests/test_pygemma.py:195-212,:253-295): n=1000, 12 covariates of which one IS the
+    SNP (x appears twice in W*), so the x pivot is ~0 and the MIN_VAL clamps (pyx:939-961) decide beta/se.  The live-path
+    functions must still reproduce the reference: quadratic forms, d1, newton, lambda, and the DataFrame row."""
+    import ctypes
+    L = O.lib()
+    z = np.load(os.path.join(G, "reference_test_matrices.npz"))
+    d, xr, Y, W = z["d"], z["x"], np.ascontiguousarray(z["Y"].reshape(-1)), z["W"]
+    Wx = np.ascontiguousarray(np.c_[W, xr])
+    n, ctot = Wx.shape
+    nbad = 0
+    for li, lam in enumerate(z["lams"]):
+        for full in (0, 1):
+            r = O.precompute_mat(lam, d, Wx, Y, full=bool(full), order=0)
+            k = f"l{li}_f{full}_"
+            for mine, key in ((r["yt_Pi_y"], "yPy"), (r["yt_Pi_Pi_y"], "yPPy"), (r["tr_Pi"], "trP")):
+                bad, tot = _cmp(mine, z[k + key])
+                nbad += bad
+        v = np.float32(L.orc_wrapper_d1(np.float32(lam), d, Y, Wx, n, ctot, 0))
+        # cancellation noise of the collinear column reaches d1 through yPPy: a few per cent, never the sign
+        assert np.sign(v) == np.sign(z[f"l{li}_d1"]) and abs(float(v) - float(z[f"l{li}_d1"])) <= 5e-2 * abs(float(z[f"l{li}_d1"]))
+    assert nbad <= 40          # a collinear column makes the last two levels pure cancellation noise; the others agree
+    ne = np.zeros(2, np.int64)
+    for grid, key in ((0, "calc_lambda_restricted"), (1, "calc_lambda_restricted_grid")):
+        lam = L.orc_calc_lambda_restricted(d, Y, Wx, n, ctot, grid, 0, ne)
+        assert np.float64(np.float32(lam)) == z[key]
+    r = O.calculate(d, Y, W, xr.reshape(-1, 1), grid=False, order=0, nthreads=1)
+    assert r["lambda"][0] == z["df_lambda"][0]
+    for col in ("beta", "se_beta", "tau"):
+        a, b = float(r[col][0]), float(z["df_" + col][0])
+        assert np.isfinite(a) == np.isfinite(b)
+        # the x pivot is the difference of two ~equal numbers: agreement to a few per cent is all that is defined here
+        assert abs(a - b) <= (1e-4 if col == "tau" else 5e-2) * abs(b)
