@@ -6,29 +6,27 @@
 //
 // The codes are exact in bf16, so U' code needs only U split into three bf16 planes U = U1 + U2 + U3 (8 + 8 + 8
 // significant bits): every product code*U_s is exact in fp32 and the three partial GEMMs accumulate into ONE fp32
-// accumulator on the bf16 MFMA pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32-MFMA rate; 3 passes => 5.3x fewer
+// accumulator on the bf16 MFMA pipe (v_mfma_f32_16x16x32_bf16, 16x the fp32-MFMA rate; 3 passes => 5.3x fewer
 // matrix cycles than the fp32 path).  Error class = fp32 accumulation, the same as the fp32-MFMA kernel and as the
 // reference's sgemm (lmm/lmm.py:244); the split drops < 2^-24 |U|.  U'1 is taken in fp64.
 //
 // Layout: both operands K-contiguous ("NT" GEMM): Gt [p][ldk] bf16 codes (SNP-major), Up [n][3*KT*GBK] bf16 with the
 // three planes of each 64-sample K-tile interleaved, so the kernel is a plain GEMM over K' = 3K whose A tile index is
-// kt'/3.  128x128 tile, 4 waves x (2x2) 32x32 MFMA tiles, BK = 64, LDS rows padded to 144 B (conflict-free
-// ds_read_b128), register-staged double buffering.
+// kt'/3.  256 (SNPs) x 128 (eigen index) tile per 512-thread workgroup, 8 waves as 4x2, each 64x64 = 4x4
+// v_mfma_f32_16x16x32_bf16 tiles (the 16x16x32 shape sustains a higher clock than 32x32x16 at equal cycles per flop),
+// BK = 64, operands staged by LDS-DMA into an XOR-swizzled ring (see rotate_geno_kernel).
 #include "common.hpp"
 
 namespace pg {
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef PG_GBK
 #define PG_GBK 64
 #endif
-#ifndef PG_GBLK
-#define PG_GBLK 2
-#endif
-constexpr int GBM = 128, GBN = 128, GBK = PG_GBK, GROWB = GBK * 2 + 16;   // LDS row bytes (padded)
-constexpr int GCH = GBK / 8, GRPP = 256 / GCH, GNH = 128 / GRPP;          // 16-B chunks per row, rows per staging pass, passes
+constexpr int GBM = 256, GBN = 128, GBK = PG_GBK;
+static_assert(GBK == 64, "the LDS image is 128-byte rows: 64 bf16 per K-tile");
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rn(float f)
 {
@@ -154,92 +152,138 @@ struct GenoParams {
     int tiles_m, tiles_n, KT3;
 };
 
-__global__ __launch_bounds__(256, PG_GBLK) void rotate_geno_kernel(GenoParams gp)
+// LDS image of a 128-row x 64-k bf16 tile: plain 128-byte rows (what the LDS-DMA writes: a wave instruction fills
+// 1 KB = 8 consecutive rows, lane L -> row L/8, 16-byte chunk L%8), with the chunk index XOR-swizzled by (row>>1)&7.
+// The swizzle is applied on the GLOBAL source address of the DMA (the LDS side stays lane-linear) and again on the
+// read address, so the 16 rows a ds_read_b128 lane group touches fall on 16 different bank quads.
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// Staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of THREE U-plane
+// buffers (128 rows) and two genotype buffers (256 rows), with the DMA of stage s+2 left in flight across the barrier of stage s:
+//   stage s:  issue DMA(s+2) -> ring[(s+2)%3]      (that buffer was last read in stage s-1, behind the last barrier)
+//             MFMAs of stage s from ring[s%3]
+//             s_waitcnt vmcnt(#DMA issued in THIS stage)   => everything older, i.e. DMA(s+1), has landed
+//             raw s_barrier                               => every wave's share of DMA(s+1) has landed; ring[s%3] is free
+// __syncthreads() would drain the DMA with vmcnt(0) at every barrier (the ~900 TF ceiling of the two-barrier structure).
+__global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char As[2][GBM * GROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][GBN * GROWB];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * 128 * 128 + 2 * 256 * 128];
+    unsigned char *const Bs = lds, *const As = lds + 3 * 128 * 128;
     const int T = gp.tiles_m * gp.tiles_n;
     const int b = blockIdx.x;
     const int q = T / 8, r = T % 8, xcd = b % 8;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-    const int per_group = 8 * gp.tiles_n;
-    const int grp = lid / per_group, first_m = grp * 8;
-    const int gsz = (gp.tiles_m - first_m) < 8 ? (gp.tiles_m - first_m) : 8;
+    const int per_group = 4 * gp.tiles_n;
+    const int grp = lid / per_group, first_m = grp * 4;
+    const int gsz = (gp.tiles_m - first_m) < 4 ? (gp.tiles_m - first_m) : 4;
     const int tm = first_m + (lid % per_group) % gsz, tn = (lid % per_group) / gsz;
     const long long m0 = (long long)tm * GBM, n0 = (long long)tn * GBN;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
 
-    floatx16 acc[2][2];
+    floatx4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+            for (int e = 0; e < 4; e++) acc[i][j][e] = 0.0f;
 
-    // staging: 128 rows x 128 B per operand per stage = 1024 x 16 B; 256 threads x 4
-    const int srow = tid / GCH, schunk = tid % GCH;     // rows srow + GRPP*h, 16-byte chunk schunk
-    // The genotype tile of a K-tile serves all three U planes: it is staged once per K-tile (buffer (kt3/3)&1),
-    // only the U-plane tile changes every stage — a third less LDS-write traffic, which is what bounds this loop.
-    uint4 ra[GNH], rb[GNH];
-    auto gload = [&](int kt3) {
-        const long long kb = (long long)kt3 * GBK;                // B: plane-interleaved U tiles
+    // wave w fills rows 32w .. 32w+31 of a tile, 8 rows per DMA instruction; rows past the end of the operand are
+    // clamped (their outputs are never stored)
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    const unsigned char *gA[4], *gB[2];
 #pragma unroll
-        for (int h = 0; h < GNH; h++) {
-            const long long rown = n0 + srow + GRPP * h;
-            rb[h] = (rown < gp.n) ? *reinterpret_cast<const uint4 *>(gp.Up + rown * gp.ldp + kb + schunk * 8) : make_uint4(0, 0, 0, 0);
+    for (int t = 0; t < 4; t++) {
+        const int row = wave * 32 + 8 * t + lrow;          // 8 waves x 32 rows = 256 genotype rows
+        long long rm = m0 + row;
+        rm = rm < gp.p ? rm : gp.p - 1;
+        gA[t] = reinterpret_cast<const unsigned char *>(gp.Gt + rm * gp.ldk) + swz(row, lchunk) * 16;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int row = wave * 16 + 8 * t + lrow;          // 8 waves x 16 rows = 128 U rows
+        long long rn = n0 + row;
+        rn = rn < gp.n ? rn : gp.n - 1;
+        gB[t] = reinterpret_cast<const unsigned char *>(gp.Up + rn * gp.ldp) + swz(row, lchunk) * 16;
+    }
+    auto dmaB = [&](int kt3) {
+        unsigned char *dst = Bs + (kt3 % 3) * (128 * 128) + (wave * 16) * 128;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gB[t] + (size_t)kt3 * GBK * 2),
+                                             (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
+    };
+    auto dmaA = [&](int ktile) {
+        unsigned char *dst = As + (ktile & 1) * (256 * 128) + (wave * 32) * 128;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gA[t] + (size_t)ktile * GBK * 2),
+                                             (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
+    };
+    // prologue: stages 0 and 1 (stage 1 stays in flight)
+    dmaA(0); dmaB(0);
+    if (gp.KT3 > 1) dmaB(1);
+    if (gp.KT3 > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa[2][4];   // genotype fragments: read at plane 0 of a K-tile, reused for its three U planes
+    for (int ktile = 0; ktile < gp.KT3 / 3; ktile++) {
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) {
+        const int kt = 3 * ktile + pl;
+        const unsigned char *Bcur = Bs + pl * (128 * 128), *Acur = As + (ktile & 1) * (256 * 128);
+        int issued = 0;
+        if (kt + 2 < gp.KT3) {
+            dmaB(kt + 2); issued = 2;
+            if ((kt + 2) % 3 == 0) { dmaA((kt + 2) / 3); issued = 6; }   // genotype tile of the K-tile starting at stage kt+2
         }
-        if (kt3 % 3 == 0) {
-            const long long ka = (long long)(kt3 / 3) * GBK;      // A: genotype codes of K-tile kt3/3
+        // all 16 operand fragments of the stage first (one LDS latency per stage), then 32 MFMAs back to back
+        // 16x16x32 operand: lane l holds row (l & 15), k = 32*ks + 8*(l >> 4) .. +7 = logical 16-byte chunk 4*ks + (l >> 4)
+        bf16x8 fb[2][4];
 #pragma unroll
-            for (int h = 0; h < GNH; h++) {
-                const long long rowm = m0 + srow + GRPP * h;
-                ra[h] = (rowm < gp.p) ? *reinterpret_cast<const uint4 *>(gp.Gt + rowm * gp.ldk + ka + schunk * 8) : make_uint4(0, 0, 0, 0);
+        for (int ks = 0; ks < 2; ks++) {
+            const int chunk = 4 * ks + (lane >> 4);
+            if (pl == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int row = wm * 64 + i * 16 + (lane & 15);
+                    fa[ks][i] = *reinterpret_cast<const bf16x8 *>(Acur + row * 128 + swz(row, chunk) * 16);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = wn * 64 + j * 16 + (lane & 15);
+                fb[ks][j] = *reinterpret_cast<const bf16x8 *>(Bcur + row * 128 + swz(row, chunk) * 16);
             }
         }
-    };
-    auto lstore = [&](int kt3) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int h = 0; h < GNH; h++) *reinterpret_cast<uint4 *>(&Bs[kt3 & 1][(srow + GRPP * h) * GROWB + schunk * 16]) = rb[h];
-        if (kt3 % 3 == 0) {
+        for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-            for (int h = 0; h < GNH; h++) *reinterpret_cast<uint4 *>(&As[(kt3 / 3) & 1][(srow + GRPP * h) * GROWB + schunk * 16]) = ra[h];
-        }
-    };
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < gp.KT3; kt++) {
-        const int buf = kt & 1, abuf = (kt / 3) & 1;
-        if (kt + 1 < gp.KT3) gload(kt + 1);
+            for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int kk = 0; kk < GBK; kk += 16) {
-            // 32x32x16 operand: lane l holds row (l & 31), k = kk + 8*(l >> 5) .. +7  (16 bytes)
-            const int koff = (kk + 8 * (lane >> 5)) * 2;
-            bf16x8 a[2], bb[2];
-#pragma unroll
-            for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const bf16x8 *>(&As[abuf][(wm * 64 + i * 32 + (lane & 31)) * GROWB + koff]);
-#pragma unroll
-            for (int j = 0; j < 2; j++) bb[j] = *reinterpret_cast<const bf16x8 *>(&Bs[buf][(wn * 64 + j * 32 + (lane & 31)) * GROWB + koff]);
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < gp.KT3) lstore(kt + 1);
-        __syncthreads();
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        // retire everything but this stage's own DMA, then meet the other waves (LDS reads of this stage are complete:
+        // their values fed the MFMAs above)
+        if (issued == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
     }
     // epilogue: Xr[g][k] = v0_g * (U'1)_k + dx_g * acc   (fp64 combine, one rounding to fp32); pad columns zero
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const long long col = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < 4; j++) {
+            const long long col = n0 + wn * 64 + j * 16 + (lane & 15);
             const double ck = (col < gp.n) ? gp.colsum[col] : 0.0;
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const long long row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            for (int e = 0; e < 4; e++) {
+                const long long row = m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + e;
                 if (row < gp.p && col < gp.ldx) {
                     const double v = (col < gp.n) ? fma((double)gp.dx[row], (double)acc[i][j][e], (double)gp.v0[row] * ck) : 0.0;
                     gp.Xr[row * gp.ldx + col] = (float)v;
@@ -311,7 +355,7 @@ extern "C" int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void 
     gp.tiles_m = (int)((p + GBM - 1) / GBM); gp.tiles_n = (int)((n + GBN - 1) / GBN); gp.KT3 = (int)(3 * kt);
     const long long T = (long long)gp.tiles_m * gp.tiles_n;
     PG_REQUIRE(T < (1LL << 31), "pg_rotate_geno_dev: too many tiles");
-    rotate_geno_kernel<<<dim3((unsigned)T), 256, 0, ctx->stream>>>(gp);
+    rotate_geno_kernel<<<dim3((unsigned)T), 512, 0, ctx->stream>>>(gp);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
