@@ -167,7 +167,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 // __syncthreads() would drain the DMA with vmcnt(0) at every barrier (the ~900 TF ceiling of the two-barrier structure).
 __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * 128 * 128 + 2 * 256 * 128];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * 128 * 128 + 256 * 128];
     unsigned char *const Bs = lds, *const As = lds + 3 * 128 * 128;
     const int T = gp.tiles_m * gp.tiles_n;
     const int b = blockIdx.x;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
                                              (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
     };
     auto dmaA = [&](int ktile) {
-        unsigned char *dst = As + (ktile & 1) * (256 * 128) + (wave * 32) * 128;
+        unsigned char *dst = As + (wave * 32) * 128;
 #pragma unroll
         for (int t = 0; t < 4; t++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gA[t] + (size_t)ktile * GBK * 2),
@@ -226,18 +226,27 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
     if (gp.KT3 > 1) dmaB(1);
     if (gp.KT3 > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // Ping-pong: waves 0-3 ("early") and 4-7 ("late") sit one per SIMD and run half a stage apart, so that while one
+    // wave of a SIMD issues its 32 MFMAs the other issues its DMA and reads its fragments:
+    //   phase 2t   : early mem(t)   | late mfma(t-1)
+    //   phase 2t+1 : early mfma(t)  | late mem(t)          (one s_barrier between consecutive phases)
+    // mem(t) = issue DMA(t+2), read the fragments of stage t into registers, wait until the own share of DMA(t+1)
+    // has landed.  ring[(t+2)%3] was last read in late mem(t-1) = phase 2t-1: free.  The genotype fragments live in
+    // registers for the three planes of a K-tile, so the single genotype buffer (read only at plane 0, phases 6T and
+    // 6T+1) is refilled from phase 6T+2 on.
+    const bool late = wave >= 4;
+    if (late) __builtin_amdgcn_s_barrier();
     bf16x8 fa[2][4];   // genotype fragments: read at plane 0 of a K-tile, reused for its three U planes
     for (int ktile = 0; ktile < gp.KT3 / 3; ktile++) {
 #pragma unroll
       for (int pl = 0; pl < 3; pl++) {
         const int kt = 3 * ktile + pl;
-        const unsigned char *Bcur = Bs + pl * (128 * 128), *Acur = As + (ktile & 1) * (256 * 128);
+        const unsigned char *Bcur = Bs + pl * (128 * 128);
         int issued = 0;
         if (kt + 2 < gp.KT3) {
             dmaB(kt + 2); issued = 2;
-            if ((kt + 2) % 3 == 0) { dmaA((kt + 2) / 3); issued = 6; }   // genotype tile of the K-tile starting at stage kt+2
+            if (pl == 1) { dmaA(ktile + 1); issued = 6; }   // genotype tile of the K-tile starting at stage kt+2
         }
-        // all 16 operand fragments of the stage first (one LDS latency per stage), then 32 MFMAs back to back
         // 16x16x32 operand: lane l holds row (l & 15), k = 32*ks + 8*(l >> 4) .. +7 = logical 16-byte chunk 4*ks + (l >> 4)
         bf16x8 fb[2][4];
 #pragma unroll
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int row = wm * 64 + i * 16 + (lane & 15);
-                    fa[ks][i] = *reinterpret_cast<const bf16x8 *>(Acur + row * 128 + swz(row, chunk) * 16);
+                    fa[ks][i] = *reinterpret_cast<const bf16x8 *>(As + row * 128 + swz(row, chunk) * 16);
                 }
             }
 #pragma unroll
@@ -256,6 +265,12 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
                 fb[ks][j] = *reinterpret_cast<const bf16x8 *>(Bcur + row * 128 + swz(row, chunk) * 16);
             }
         }
+        if (issued == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -265,15 +280,12 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        // retire everything but this stage's own DMA, then meet the other waves (LDS reads of this stage are complete:
-        // their values fed the MFMAs above)
-        if (issued == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (!late) __builtin_amdgcn_s_barrier();
     // epilogue: Xr[g][k] = v0_g * (U'1)_k + dx_g * acc   (fp64 combine, one rounding to fp32); pad columns zero
 #pragma unroll
     for (int i = 0; i < 4; i++)
