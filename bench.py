@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 from pygemma_amd import _lib, synth  # noqa: E402
 
 F32_MFMA_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU
-BF16_MFMA_PEAK_TF = 2500.0 # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+BF16_MFMA_PEAK_TF = 2500.0 # dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md)
 F64_VALU_PEAK_TF = 78.6    # fp64 vector peak (= fp64 matrix peak on MI355X): 128 FLOP/clk/CU
 
 
@@ -252,7 +252,7 @@ def main():
         "metric": "SNPs/sec (whole node) at n=10,000 c=5; K-eigendecomp wallclock",
         "value": value, "unit": "SNPs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16x3->f32 (genotype rotation) | f32 (general rotation) + f64 (Gram/sweeps)", "data": "synthetic",
+        "dtype": "f16x2->f32 (genotype rotation) | f32 (general rotation) + f64 (Gram/sweeps)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: synthetic n={n}, c={c}, {B} SNPs/GPU/step: rotate (U'X) + REML "
                                f"{'grid' if a.grid else 'decade-scan+Brent+Newton'} + Wald F + p on device"
                                + ("; RCCL all-gather of result rows" if world > 1 else ""),
@@ -260,11 +260,11 @@ def main():
                    "parallelism": f"snp-shards x{world}"},
         "eigh_seconds": min(eigh_s),
         "eigh_note": "fp64 Householder tridiagonalisation + divide&conquer + back-transform on device, n=%d, one-time" % n,
-        "roofline": ({"kernel": "rotate_geno_kernel (+detect/encode): bf16 MFMA 32x32x16, U split in 3 bf16 planes, fp32 accumulate",
-                      "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12, "peak": BF16_MFMA_PEAK_TF / 3.0, "unit": "TFLOP/s",
-                      "frac": rot_flops / rot_avg / 1e12 / (BF16_MFMA_PEAK_TF / 3.0),
-                      "peak_note": "algorithmic 2n^2 flop/SNP against the dense bf16 MFMA peak (2500 TF) divided by the 3 bf16 passes an "
-                                   "fp32-exact U needs; executed bf16 rate = 3x achieved",
+        "roofline": ({"kernel": "rotate_geno_kernel (+detect/encode): fp16 MFMA 16x16x32, U split in 2 fp16 planes, fp32 accumulate",
+                      "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12, "peak": BF16_MFMA_PEAK_TF / 2.0, "unit": "TFLOP/s",
+                      "frac": rot_flops / rot_avg / 1e12 / (BF16_MFMA_PEAK_TF / 2.0),
+                      "peak_note": "algorithmic 2n^2 flop/SNP against the dense fp16 MFMA peak (2500 TF) divided by the 2 fp16 passes a "
+                                   "24-bit U needs; executed fp16 rate = 2x achieved",
                       "traffic": pmc_traffic("rotate_geno_kernel") if (n, B) == (10000, 16384) else None,
                       "algorithmic_bytes": 4.0 * n * B + 4.0 * n * n + 4.0 * ldx * B, "avg_launch_ms": rot_avg * 1e3}
                      if geno_used[1] else
@@ -276,7 +276,7 @@ def main():
                                  "achieved": rot_flops / t_f32 / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": rot_flops / t_f32 / 1e12 / F32_MFMA_PEAK_TF, "avg_launch_ms": t_f32 * 1e3,
                                  "traffic": pmc_traffic("rotate_kernel") if (n, B) == (10000, 16384) else None},
-        "rotation_path": "genotype bf16x3" if geno_used[1] else "fp32 MFMA",
+        "rotation_path": "genotype f16x2" if geno_used[1] else "fp32 MFMA",
         "roofline_assoc": {"kernel": "assoc_kernel<%d> (+setup, p-values; fp64 VALU)" % c, "bound": "mfma",
                            "achieved": assoc_flops_snp * B / assoc_avg / 1e12, "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
                            "frac": assoc_flops_snp * B / assoc_avg / 1e12 / F64_VALU_PEAK_TF,

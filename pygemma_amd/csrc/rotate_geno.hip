@@ -4,44 +4,74 @@
 //
 //   x_g = v0_g + dx_g * code_g,  code in {0,1,2}   =>   U'x_g = v0_g * (U'1) + dx_g * (U' code_g)
 //
-// The codes are exact in bf16, so U' code needs only U split into three bf16 planes U = U1 + U2 + U3 (8 + 8 + 8
-// significant bits): every product code*U_s is exact in fp32 and the three partial GEMMs accumulate into ONE fp32
-// accumulator on the bf16 MFMA pipe (v_mfma_f32_16x16x32_bf16, 16x the fp32-MFMA rate; 3 passes => 5.3x fewer
-// matrix cycles than the fp32 path).  Error class = fp32 accumulation, the same as the fp32-MFMA kernel and as the
-// reference's sgemm (lmm/lmm.py:244); the split drops < 2^-24 |U|.  U'1 is taken in fp64.
+// The codes are exact in fp16, so U' code needs only U split into two fp16 planes, S*U = H1 + H2 + e with S the power of two that puts S*max|U| in [2^14, 2^15)
+// (keeps H2 out of the fp16 subnormals) and round-to-nearest at both steps: |e| <= 2^-24 |S*U| — the size of fp32's own
+// quantisation of U (measured: the split adds 0.6x the error U already carries from its rounding to fp32, and 1/20 of
+// the fp32 accumulation error).  Every product code*H is exact in fp32 and the two partial GEMMs accumulate into ONE fp32
+// accumulator on the fp16 MFMA pipe (v_mfma_f32_16x16x32_f16, 16x the fp32-MFMA rate; 2 passes => 8x fewer matrix
+// cycles than the fp32 path).  Error class = fp32 accumulation, the same as the fp32-MFMA kernel and as the reference's
+// sgemm (lmm/lmm.py:244).  U'1 is taken in fp64.
 //
-// Layout: both operands K-contiguous ("NT" GEMM): Gt [p][ldk] bf16 codes (SNP-major), Up [n][3*KT*GBK] bf16 with the
-// three planes of each 64-sample K-tile interleaved, so the kernel is a plain GEMM over K' = 3K whose A tile index is
-// kt'/3.  256 (SNPs) x 128 (eigen index) tile per 512-thread workgroup, 8 waves as 4x2, each 64x64 = 4x4
-// v_mfma_f32_16x16x32_bf16 tiles (the 16x16x32 shape sustains a higher clock than 32x32x16 at equal cycles per flop),
+// Layout: both operands K-contiguous ("NT" GEMM): Gt [p][ldk] fp16 codes (SNP-major), Up [n][2*KT*GBK] fp16 with the
+// two planes of each 64-sample K-tile interleaved, so the kernel is a plain GEMM over K' = 2K whose A tile index is
+// kt'/2.  256 (SNPs) x 128 (eigen index) tile per 512-thread workgroup, 8 waves as 4x2, each 64x64 = 4x4
+// v_mfma_f32_16x16x32_f16 tiles (the 16x16x32 shape sustains a higher clock than 32x32x16 at equal cycles per flop),
 // BK = 64, operands staged by LDS-DMA into an XOR-swizzled ring (see rotate_geno_kernel).
 #include "common.hpp"
 
 namespace pg {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 
 #ifndef PG_GBK
 #define PG_GBK 64
 #endif
 constexpr int GBM = 256, GBN = 128, GBK = PG_GBK;
-static_assert(GBK == 64, "the LDS image is 128-byte rows: 64 bf16 per K-tile");
+static_assert(GBK == 64, "the LDS image is 128-byte rows: 64 fp16 per K-tile");
 
-__device__ __forceinline__ unsigned short f32_to_bf16_rn(float f)
+__device__ __forceinline__ unsigned short f32_to_f16_rn(float f)
 {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);       // round to nearest even (inputs are finite)
-    return (unsigned short)(u >> 16);
+    const _Float16 h = (_Float16)f;        // v_cvt_f16_f32: round to nearest even
+    unsigned short b;
+    __builtin_memcpy(&b, &h, 2);
+    return b;
 }
-__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ float f16_to_f32(unsigned short b)
+{
+    _Float16 h;
+    __builtin_memcpy(&h, &b, 2);
+    return (float)h;
+}
 
-// U (n x n, row stride ldU, eigenvector k in column k) -> Up[k][kt][plane][j] (bf16) and colsum[k] = sum_i U[i][k] (fp64)
-__global__ __launch_bounds__(256) void split_u_kernel(long long n, long long ldU, const float *U, unsigned short *Up, long long ldp, double *colsum)
+// max |U| as an int key (order-independent), then the power-of-two scale S: S*max|U| in (2^14, 2^15]
+__global__ void absmax_kernel(long long n, long long ldU, const float *U, int *key)
+{
+    int m = 0;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n * n; idx += (long long)gridDim.x * blockDim.x) {
+        const int b = __float_as_int(U[(idx / n) * ldU + idx % n]) & 0x7FFFFFFF;
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(key, m);
+}
+__global__ void scale_kernel(const int *key, float *scale)
+{
+    const int e = ((*key) >> 23) & 0xFF;                 // biased exponent of max|U| (NaN/inf keys are rejected by the caller's flag)
+    int se = 127 + 14 - (e - 127);                       // S = 2^(14 - floor(log2 max)): S*max in [2^14, 2^15)
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    scale[0] = __int_as_float(se << 23);
+    scale[1] = __int_as_float((254 - se) << 23);         // 1/S
+}
+
+// U (n x n, row stride ldU, eigenvector k in column k) -> Up[k][kt][plane][j] (fp16 planes of S*U) and colsum[k] = sum_i U[i][k] (fp64)
+__global__ __launch_bounds__(256) void split_u_kernel(long long n, long long ldU, const float *U, unsigned short *Up, long long ldp, double *colsum,
+                                                      const float *scale)
 {
     __shared__ float tile[64][65];
     const long long k0 = (long long)blockIdx.x * 64, i0 = (long long)blockIdx.y * 64;   // eigen index block, sample block (= K-tile)
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float S = scale[0];
     for (int r = ty; r < 64; r += 4) {
         const long long i = i0 + r, k = k0 + tx;
         tile[r][tx] = (i < n && k < n) ? U[i * ldU + k] : 0.0f;
@@ -50,14 +80,12 @@ __global__ __launch_bounds__(256) void split_u_kernel(long long n, long long ldU
     for (int r = ty; r < 64; r += 4) {      // r: eigen index within block, tx: sample within K-tile
         const long long k = k0 + r;
         if (k >= n) continue;
-        const float u = tile[tx][r];
-        const unsigned short h1 = f32_to_bf16_rn(u);
-        const float r1 = u - bf16_to_f32(h1);
-        const unsigned short h2 = f32_to_bf16_rn(r1);
-        const float r2 = r1 - bf16_to_f32(h2);
-        const unsigned short h3 = f32_to_bf16_rn(r2);
-        unsigned short *dst = Up + k * ldp + (long long)blockIdx.y * 3 * GBK;
-        dst[tx] = h1; dst[GBK + tx] = h2; dst[2 * GBK + tx] = h3;
+        const float u = tile[tx][r] * S;                     // exact (power of two)
+        const unsigned short h1 = f32_to_f16_rn(u);
+        const float r1 = u - f16_to_f32(h1);                 // exact
+        const unsigned short h2 = f32_to_f16_rn(r1);
+        unsigned short *dst = Up + k * ldp + (long long)blockIdx.y * 2 * GBK;
+        dst[tx] = h1; dst[GBK + tx] = h2;
     }
     // column sums (fp64), one wave per 16 eigen indices, deterministic order over the 64 samples, atomics across K-tiles avoided:
     // each (k, K-tile) partial is written to colsum workspace by the caller's reduce (see launch): here accumulate via atomicAdd-free path
@@ -79,7 +107,7 @@ __global__ void colsum_reduce_kernel(long long n, int kt, double *colsum)
 // Genotype detection + encoding in three passes, all parallel over rows and columns:
 //   minmax : per column lowest / highest value (order-independent atomics on an order-preserving int key)
 //   encode : code = 0 (lowest), 2 (highest), 1 (anything else: must sit at the midpoint within 8 ulp, else the block
-//            is not a genotype block), transposed to SNP-major bf16 Gt [p][ldk] through a 32x32 LDS tile; pad zeroed
+//            is not a genotype block), transposed to SNP-major fp16 Gt [p][ldk] through a 32x32 LDS tile; pad zeroed
 //   params : v0 = lowest, dx = (highest - lowest)/2  ->  x = v0 + dx*code for one-, two- and three-valued columns alike
 __device__ __forceinline__ int f2key(float f) { int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float key2f(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
@@ -123,8 +151,8 @@ __global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long
         if (i < n && g < p) {
             const float x = X[i * ldX + g];
             if (x == lo) code = 0;
-            else if (x == hv) code = 0x4000;                       // bf16 2.0
-            else { code = 0x3F80; if (!(fabsf(x - mid) <= tol)) bad = true; }   // bf16 1.0
+            else if (x == hv) code = 0x4000;                       // fp16 2.0
+            else { code = 0x3C00; if (!(fabsf(x - mid) <= tol)) bad = true; }   // fp16 1.0
         }
         tile[r][tx] = code;
     }
@@ -149,26 +177,33 @@ struct GenoParams {
     const float *v0, *dx;
     const double *colsum;
     float *Xr;
-    int tiles_m, tiles_n, KT3;
+    int tiles_m, tiles_n, KT;   // KT = K-tiles of 64 samples; stages = 2*KT (two U planes per K-tile)
+    const float *scale;         // {S, 1/S}
 };
 
-// LDS image of a 128-row x 64-k bf16 tile: plain 128-byte rows (what the LDS-DMA writes: a wave instruction fills
+// LDS image of a 128-row x 64-k fp16 tile: plain 128-byte rows (what the LDS-DMA writes: a wave instruction fills
 // 1 KB = 8 consecutive rows, lane L -> row L/8, 16-byte chunk L%8), with the chunk index XOR-swizzled by (row>>1)&7.
 // The swizzle is applied on the GLOBAL source address of the DMA (the LDS side stays lane-linear) and again on the
 // read address, so the 16 rows a ds_read_b128 lane group touches fall on 16 different bank quads.
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-// Staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of THREE U-plane
-// buffers (128 rows) and two genotype buffers (256 rows), with the DMA of stage s+2 left in flight across the barrier of stage s:
-//   stage s:  issue DMA(s+2) -> ring[(s+2)%3]      (that buffer was last read in stage s-1, behind the last barrier)
-//             MFMAs of stage s from ring[s%3]
-//             s_waitcnt vmcnt(#DMA issued in THIS stage)   => everything older, i.e. DMA(s+1), has landed
-//             raw s_barrier                               => every wave's share of DMA(s+1) has landed; ring[s%3] is free
-// __syncthreads() would drain the DMA with vmcnt(0) at every barrier (the ~900 TF ceiling of the two-barrier structure).
+// Staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of FOUR U-plane
+// buffers (128 rows; stage t = plane t&1 of K-tile t>>1 lives in ring[t&3]) and two genotype buffers (256 rows), with the
+// DMA of stage t+2 in flight across the barriers of stage t.  Waits are counted (`s_waitcnt vmcnt(#issued this stage)`
+// retires everything older) and the barriers are raw s_barrier: __syncthreads() would drain the DMA at every barrier.
+//
+// Ping-pong: waves 0-3 ("early") and 4-7 ("late") sit one per SIMD and run half a stage apart, so that while one wave of
+// a SIMD issues its 32 MFMAs the other issues its DMA and reads its fragments:
+//   phase 2t   : early mem(t)   | late mfma(t-1)
+//   phase 2t+1 : early mfma(t)  | late mem(t)          (one s_barrier between consecutive phases)
+// mem(t) = issue DMA(t+2) [+ the genotype tile two K-tiles ahead, at plane 1], read the fragments of stage t into
+// registers, wait until the own share of everything issued before this stage has landed.  ring[(t+2)&3] was last read in
+// mem(t-2); the genotype fragments live in registers for both planes of a K-tile, and genotype buffer T&1 (read only at
+// plane 0 of tile T) is refilled with tile T+2 from plane 1 of tile T on.
 __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * 128 * 128 + 256 * 128];
-    unsigned char *const Bs = lds, *const As = lds + 3 * 128 * 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 128 * 128 + 2 * 256 * 128];
+    unsigned char *const Bs = lds, *const As = lds + 4 * 128 * 128;
     const int T = gp.tiles_m * gp.tiles_n;
     const int b = blockIdx.x;
     const int q = T / 8, r = T % 8, xcd = b % 8;
@@ -180,6 +215,7 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
     const long long m0 = (long long)tm * GBM, n0 = (long long)tn * GBN;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
+    const int KT2 = 2 * gp.KT;
 
     floatx4 acc[4][4];
 #pragma unroll
@@ -189,66 +225,61 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 #pragma unroll
             for (int e = 0; e < 4; e++) acc[i][j][e] = 0.0f;
 
-    // wave w fills rows 32w .. 32w+31 of a tile, 8 rows per DMA instruction; rows past the end of the operand are
-    // clamped (their outputs are never stored)
+    // wave w fills rows 32w .. 32w+31 of a genotype tile and rows 16w .. 16w+15 of a U-plane tile, 8 rows per DMA
+    // instruction; rows past the end of the operand are clamped (their outputs are never stored)
     const int lrow = lane >> 3, lchunk = lane & 7;
     const unsigned char *gA[4], *gB[2];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        const int row = wave * 32 + 8 * t + lrow;          // 8 waves x 32 rows = 256 genotype rows
+        const int row = wave * 32 + 8 * t + lrow;
         long long rm = m0 + row;
         rm = rm < gp.p ? rm : gp.p - 1;
         gA[t] = reinterpret_cast<const unsigned char *>(gp.Gt + rm * gp.ldk) + swz(row, lchunk) * 16;
     }
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-        const int row = wave * 16 + 8 * t + lrow;          // 8 waves x 16 rows = 128 U rows
+        const int row = wave * 16 + 8 * t + lrow;
         long long rn = n0 + row;
         rn = rn < gp.n ? rn : gp.n - 1;
         gB[t] = reinterpret_cast<const unsigned char *>(gp.Up + rn * gp.ldp) + swz(row, lchunk) * 16;
     }
-    auto dmaB = [&](int kt3) {
-        unsigned char *dst = Bs + (kt3 % 3) * (128 * 128) + (wave * 16) * 128;
+    auto dmaB = [&](int stage) {
+        unsigned char *dst = Bs + (stage & 3) * (128 * 128) + (wave * 16) * 128;
 #pragma unroll
         for (int t = 0; t < 2; t++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gB[t] + (size_t)kt3 * GBK * 2),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gB[t] + (size_t)stage * GBK * 2),
                                              (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
     };
     auto dmaA = [&](int ktile) {
-        unsigned char *dst = As + (wave * 32) * 128;
+        unsigned char *dst = As + (ktile & 1) * (256 * 128) + (wave * 32) * 128;
 #pragma unroll
         for (int t = 0; t < 4; t++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gA[t] + (size_t)ktile * GBK * 2),
                                              (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
     };
-    // prologue: stages 0 and 1 (stage 1 stays in flight)
+    // prologue: K-tile 0 (genotypes + both planes = stages 0, 1) and the genotypes of K-tile 1; only stage 0's operands
+    // have to have landed at the first barrier
     dmaA(0); dmaB(0);
-    if (gp.KT3 > 1) dmaB(1);
-    if (gp.KT3 > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dmaB(1);
+    if (gp.KT > 1) { dmaA(1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // Ping-pong: waves 0-3 ("early") and 4-7 ("late") sit one per SIMD and run half a stage apart, so that while one
-    // wave of a SIMD issues its 32 MFMAs the other issues its DMA and reads its fragments:
-    //   phase 2t   : early mem(t)   | late mfma(t-1)
-    //   phase 2t+1 : early mfma(t)  | late mem(t)          (one s_barrier between consecutive phases)
-    // mem(t) = issue DMA(t+2), read the fragments of stage t into registers, wait until the own share of DMA(t+1)
-    // has landed.  ring[(t+2)%3] was last read in late mem(t-1) = phase 2t-1: free.  The genotype fragments live in
-    // registers for the three planes of a K-tile, so the single genotype buffer (read only at plane 0, phases 6T and
-    // 6T+1) is refilled from phase 6T+2 on.
     const bool late = wave >= 4;
     if (late) __builtin_amdgcn_s_barrier();
-    bf16x8 fa[2][4];   // genotype fragments: read at plane 0 of a K-tile, reused for its three U planes
-    for (int ktile = 0; ktile < gp.KT3 / 3; ktile++) {
+    halfx8 fa[2][4];   // genotype fragments: read at plane 0 of a K-tile, reused for its second U plane
+    for (int ktile = 0; ktile < gp.KT; ktile++) {
+      const unsigned char *Apar = As + (ktile & 1) * (256 * 128), *Bpar = Bs + (ktile & 1) * (2 * 128 * 128);
 #pragma unroll
-      for (int pl = 0; pl < 3; pl++) {
-        const int kt = 3 * ktile + pl;
-        const unsigned char *Bcur = Bs + pl * (128 * 128);
+      for (int pl = 0; pl < 2; pl++) {
+        const int kt = 2 * ktile + pl;
+        const unsigned char *Bcur = Bpar + pl * (128 * 128);
         int issued = 0;
-        if (kt + 2 < gp.KT3) {
+        if (kt + 2 < KT2) {
             dmaB(kt + 2); issued = 2;
-            if (pl == 1) { dmaA(ktile + 1); issued = 6; }   // genotype tile of the K-tile starting at stage kt+2
+            if (pl == 1 && ktile + 2 < gp.KT) { dmaA(ktile + 2); issued = 6; }
         }
         // 16x16x32 operand: lane l holds row (l & 15), k = 32*ks + 8*(l >> 4) .. +7 = logical 16-byte chunk 4*ks + (l >> 4)
-        bf16x8 fb[2][4];
+        halfx8 fb[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             const int chunk = 4 * ks + (lane >> 4);
@@ -256,13 +287,13 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int row = wm * 64 + i * 16 + (lane & 15);
-                    fa[ks][i] = *reinterpret_cast<const bf16x8 *>(As + row * 128 + swz(row, chunk) * 16);
+                    fa[ks][i] = *reinterpret_cast<const halfx8 *>(Apar + row * 128 + swz(row, chunk) * 16);
                 }
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int row = wn * 64 + j * 16 + (lane & 15);
-                fb[ks][j] = *reinterpret_cast<const bf16x8 *>(Bcur + row * 128 + swz(row, chunk) * 16);
+                fb[ks][j] = *reinterpret_cast<const halfx8 *>(Bcur + row * 128 + swz(row, chunk) * 16);
             }
         }
         if (issued == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -278,7 +309,7 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -286,7 +317,8 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
       }
     }
     if (!late) __builtin_amdgcn_s_barrier();
-    // epilogue: Xr[g][k] = v0_g * (U'1)_k + dx_g * acc   (fp64 combine, one rounding to fp32); pad columns zero
+    // epilogue: Xr[g][k] = v0_g * (U'1)_k + (dx_g / S) * acc   (fp64 combine, one rounding to fp32); pad columns zero
+    const double invS = (double)gp.scale[1];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -297,7 +329,7 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
             for (int e = 0; e < 4; e++) {
                 const long long row = m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + e;
                 if (row < gp.p && col < gp.ldx) {
-                    const double v = (col < gp.n) ? fma((double)gp.dx[row], (double)acc[i][j][e], (double)gp.v0[row] * ck) : 0.0;
+                    const double v = (col < gp.n) ? fma((double)gp.dx[row] * invS, (double)acc[i][j][e], (double)gp.v0[row] * ck) : 0.0;
                     gp.Xr[row * gp.ldx + col] = (float)v;
                 }
             }
@@ -308,22 +340,27 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 
 using namespace pg;
 
-// Prepare U once per eigendecomposition: bf16 planes + fp64 column sums.  Uprep must hold pg_geno_prep_bytes(n) bytes.
+// Prepare U once per eigendecomposition: two fp16 planes of S*U + fp64 column sums + {S, 1/S}.  Uprep must hold pg_geno_prep_bytes(n) bytes.
 extern "C" size_t pg_geno_prep_bytes(int64_t n)
 {
     const long long kt = (n + GBK - 1) / GBK;
-    const size_t planes = (size_t)n * kt * 3 * GBK * 2;
+    const size_t planes = (size_t)n * kt * 2 * GBK * 2;
     const size_t sums = (size_t)(kt + 1) * n * 8;
-    return ((planes + 255) & ~(size_t)255) + sums + 256;
+    return ((planes + 255) & ~(size_t)255) + sums + 256;   // tail: {S, 1/S} floats + the max|U| key
 }
 extern "C" int pg_geno_prep_dev(pg_ctx *ctx, int64_t n, const float *U, int64_t ldU, void *Uprep)
 {
     PG_REQUIRE(ctx && U && Uprep && n > 0 && ldU >= n, "pg_geno_prep_dev: bad arguments");
     PG_HIP(hipSetDevice(ctx->device));
-    const long long kt = (n + GBK - 1) / GBK, ldp = kt * 3 * GBK;
+    const long long kt = (n + GBK - 1) / GBK, ldp = kt * 2 * GBK;
     unsigned short *Up = (unsigned short *)Uprep;
     double *colsum = (double *)((char *)Uprep + (((size_t)n * ldp * 2 + 255) & ~(size_t)255));
-    split_u_kernel<<<dim3((unsigned)((n + 63) / 64), (unsigned)kt), 256, 0, ctx->stream>>>(n, ldU, U, Up, ldp, colsum);
+    float *scale = (float *)(colsum + (size_t)(kt + 1) * n);
+    int *key = (int *)(scale + 2);
+    PG_HIP(hipMemsetAsync(key, 0, 4, ctx->stream));
+    absmax_kernel<<<1024, 256, 0, ctx->stream>>>(n, ldU, U, key);
+    scale_kernel<<<1, 1, 0, ctx->stream>>>(key, scale);
+    split_u_kernel<<<dim3((unsigned)((n + 63) / 64), (unsigned)kt), 256, 0, ctx->stream>>>(n, ldU, U, Up, ldp, colsum, scale);
     colsum_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(n, (int)kt, colsum);
     PG_HIP(hipGetLastError());
     return PG_OK;
@@ -342,7 +379,7 @@ extern "C" int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void 
     PG_REQUIRE(ctx && Uprep && X && Xr && work && is_geno_host, "pg_rotate_geno_dev: NULL argument");
     PG_REQUIRE(n > 0 && p > 0 && ldX >= p && ldx >= n && ldx <= (n + 127) / 128 * 128, "pg_rotate_geno_dev: bad shape");
     PG_HIP(hipSetDevice(ctx->device));
-    const long long kt = (n + GBK - 1) / GBK, ldk = kt * GBK, ldp = kt * 3 * GBK;
+    const long long kt = (n + GBK - 1) / GBK, ldk = kt * GBK, ldp = kt * 2 * GBK;
     unsigned short *Gt = (unsigned short *)work;
     char *tail = (char *)work + (((size_t)p * ldk * 2 + 255) & ~(size_t)255);
     float *v0 = (float *)tail, *dx = v0 + p;
@@ -362,9 +399,11 @@ extern "C" int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void 
     GenoParams gp{};
     gp.n = n; gp.p = p; gp.ldx = ldx; gp.ldk = ldk; gp.ldp = ldp;
     gp.Gt = Gt; gp.Up = (const unsigned short *)Uprep;
-    gp.colsum = (const double *)((const char *)Uprep + (((size_t)n * ldp * 2 + 255) & ~(size_t)255)) + (size_t)kt * n;
+    const double *sums = (const double *)((const char *)Uprep + (((size_t)n * ldp * 2 + 255) & ~(size_t)255));
+    gp.colsum = sums + (size_t)kt * n;
+    gp.scale = (const float *)(sums + (size_t)(kt + 1) * n);
     gp.v0 = v0; gp.dx = dx; gp.Xr = Xr;
-    gp.tiles_m = (int)((p + GBM - 1) / GBM); gp.tiles_n = (int)((n + GBN - 1) / GBN); gp.KT3 = (int)(3 * kt);
+    gp.tiles_m = (int)((p + GBM - 1) / GBM); gp.tiles_n = (int)((n + GBN - 1) / GBN); gp.KT = (int)kt;
     const long long T = (long long)gp.tiles_m * gp.tiles_n;
     PG_REQUIRE(T < (1LL << 31), "pg_rotate_geno_dev: too many tiles");
     rotate_geno_kernel<<<dim3((unsigned)T), 512, 0, ctx->stream>>>(gp);

@@ -2,7 +2,7 @@
 everything under it running on MI355X through the C ABI (include/pygemma_hip.h):
 
     eigh(K)                     -> pg_syevd_dev   (fp64 Householder + divide & conquer, lmm.py:152/197)
-    U.T @ X, U.T @ Y, U.T @ W   -> pg_rotate_geno_dev for genotype-valued SNP blocks (bf16x3 MFMA), else
+    U.T @ X, U.T @ Y, U.T @ W   -> pg_rotate_geno_dev for genotype-valued SNP blocks (f16x2 MFMA), else
                                    pg_rotate_dev  (fp32 MFMA GEMM)                      (lmm.py:243-246)
     Pool(nproc).imap(calculate) -> pg_assoc_dev   (wave-per-SNP fused lambda search + Wald test, lmm.py:378-403,461-495)
     stats.f.sf                  -> on device      (lmm.py:482)

@@ -43,7 +43,7 @@ def _geno(rng, n, p, standardise):
 
 @pytest.mark.parametrize("n,p,std", [(64, 32, True), (257, 130, True), (300, 128, False), (1000, 516, True), (2000, 200, True)])
 def test_rotate_genotype_fast_path(n, p, std, ctx):
-    """bf16x3 genotype path: error vs the fp64 rotation within the fp32-GEMM class (and no worse than the fp32-MFMA path)."""
+    """fp16x2 genotype path: error vs the fp64 rotation within the fp32-GEMM class (and no worse than the fp32-MFMA path)."""
     from pygemma_amd import ops
     rng = np.random.default_rng(n + p)
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)))

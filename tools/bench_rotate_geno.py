@@ -18,4 +18,4 @@ def run():
 run(); ts=[]
 for _ in range(5):
     t=time.time(); run(); ts.append(time.time()-t)
-t=min(ts); print(f"rotate_geno n={n} p={p} ok={ok.value}: {t*1e3:.1f} ms  {p/t:.0f} SNPs/s  ({6*n*n*p/t/1e12:.0f} bf16 TFLOP/s incl. detect+encode)")
+t=min(ts); print(f"rotate_geno n={n} p={p} ok={ok.value}: {t*1e3:.2f} ms  {p/t:.0f} SNPs/s  ({4*n*n*p/t/1e12:.0f} executed fp16 TFLOP/s incl. detect+encode)")
