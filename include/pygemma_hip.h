@@ -125,6 +125,25 @@ int pg_kinship_dev(pg_ctx *ctx, int64_t n, int64_t p_k, const float *Gt, int64_t
  * (and optionally fp64 for the invariant checks: U64/evals64 may be NULL). */
 int pg_syevd_dev(pg_ctx *ctx, int64_t n, const float *K, float *evals, float *U, double *evals64, double *U64);
 
+/* ---- Inspection surface: the model-level functions the reference's tests call directly
+ * (tests/test_pygemma.py:256-294).  One wavefront each; for fixture-level parity, not for throughput.
+ * All pointers are device pointers.  ctot = columns of Wx = the reference's np.c_[W, x] (SNP last), m = ctot + 1.
+ *
+ * pg_precompute_mat_dev : precompute_mat(lam, eigenVals, W, Y, full) (pygemma_model.pyx:880-1053).
+ *     P3/Q3/R3 : m*m*m float32 each, indexed [row][level][col] like wjt_Pi_wk / wjt_Pi_Pi_wk / wjt_Pi_Pi_Pi_wk;
+ *                entries the reference leaves undefined (np.empty) are NaN; R3 all NaN unless full.
+ *     vecs     : [5][m] = yt_Pi_y, yt_Pi_Pi_y, yt_Pi_Pi_Pi_y, tr_Pi, tr_Pi_Pi per level.
+ *     scal     : 8 floats = logdet_Wt_H_inv_W, logdet_H, then d1, d2 (NaN unless full), logL at the last level.
+ * pg_newton_dev         : newton(lam, eigenVals, Y, W, precompute=True, lambda_min, lambda_max) (pyx:1349-1416) -> *root.
+ * pg_reml_scalars_dev   : args8 = {lam, yPy, yPPy, yPPPy, trP, trPP, logdet_H, logdet_Wt_H_inv_W} ->
+ *     out3 = {likelihood_restricted_lambda_overload (pyx:1813), likelihood_derivative1_..._overload (pyx:1656),
+ *             likelihood_derivative2_..._overload (pyx:1675)} with n and c = ctot as the reference passes them. */
+int pg_precompute_mat_dev(pg_ctx *ctx, int64_t n, int ctot, float lam, const float *d, const float *Wx, const float *y,
+                          int full, float *P3, float *Q3, float *R3, float *vecs, float *scal);
+int pg_newton_dev(pg_ctx *ctx, int64_t n, int ctot, float lam, float lam_min, float lam_max, const float *d,
+                  const float *Wx, const float *y, float *root);
+int pg_reml_scalars_dev(pg_ctx *ctx, int64_t n, int ctot, const float *args8, float *out3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@ SYMBOLS = [
     "pg_ctx_destroy", "pg_ctx_sync", "pg_ctx_device", "pg_malloc", "pg_free", "pg_memcpy_h2d", "pg_memcpy_d2h",
     "pg_memset", "pg_memcpy2d_h2d", "pg_event_create", "pg_event_destroy", "pg_event_record", "pg_event_elapsed_ms",
     "pg_kinship_dev", "pg_geno_prep_bytes", "pg_geno_work_bytes", "pg_geno_prep_dev", "pg_rotate_geno_dev", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev", "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev",
+    "pg_precompute_mat_dev", "pg_newton_dev", "pg_reml_scalars_dev",
 ]
 
 
@@ -68,10 +69,15 @@ def load():
     L.pg_event_record.argtypes = [vp, vp]
     L.pg_event_elapsed_ms.argtypes = [vp, vp, vp, C.POINTER(C.c_float)]
     L.pg_syevd_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    f32 = C.c_float
+    L.pg_precompute_mat_dev.argtypes = [vp, i64, i32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.pg_newton_dev.argtypes = [vp, i64, i32, f32, f32, f32, vp, vp, vp, vp]
+    L.pg_reml_scalars_dev.argtypes = [vp, i64, i32, vp, vp]
     for name in ("pg_ctx_create", "pg_ctx_create_on_stream", "pg_ctx_sync", "pg_ctx_device", "pg_malloc", "pg_free",
                  "pg_memcpy_h2d", "pg_memcpy_d2h", "pg_memset", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev",
                  "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev", "pg_memcpy2d_h2d", "pg_event_create", "pg_event_destroy",
-                 "pg_event_record", "pg_event_elapsed_ms", "pg_kinship_dev"):
+                 "pg_event_record", "pg_event_elapsed_ms", "pg_kinship_dev", "pg_precompute_mat_dev", "pg_newton_dev",
+                 "pg_reml_scalars_dev"):
         getattr(L, name).restype = i32
     _lib = L
     return L

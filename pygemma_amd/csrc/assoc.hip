@@ -603,6 +603,35 @@ __device__ __forceinline__ double brentq_dev(Fn &&f, double xa, double xb, doubl
     return xcur;
 }
 
+// newton (pyx:1349-1416), all f32: root <- root - d1/d2; stops on the sign test (:1392), on leaving [l0, l1] (returns the
+// previous iterate, :1398-1404), on NaN/Inf (:1406), on r_eps < 1e-5 or iteration > 100 (:1411).  eval(lam, e) fills the
+// full (three-power) quadratic forms at lam.
+template <class Eval>
+__device__ __forceinline__ float newton_dev(const AssocParams &pr, float lroot, float l0, float l1, Eval &&eval)
+{
+    int iteration = 0;
+    for (;;) {
+        EvalOut e;
+        eval(lroot, e);
+        const float d1 = d1_f(pr, lroot, e.yPy, e.yPPy, e.trP);
+        const float d2 = d2_f(pr, lroot, e.yPy, e.yPPy, e.yPPPy, e.trP, e.trPP);
+        const float ratio = __fdiv_rn(d1, d2);
+        // np.sign(ratio)*np.sign(d1)*np.sign(d2) <= 0.0   (NaN compares False)
+        const bool any_nan = (ratio != ratio) || (d1 != d1) || (d2 != d2);
+        const float sr = (float)((ratio > 0) - (ratio < 0)), s1 = (float)((d1 > 0) - (d1 < 0)), s2 = (float)((d2 > 0) - (d2 < 0));
+        if (!any_nan && sr * s1 * s2 <= 0.0f) break;
+        const float lnew = __fsub_rn(lroot, ratio);
+        const float r_eps = (float)(fabs((double)__fsub_rn(lnew, lroot)) / fabs((double)lroot));
+        if (lnew < l0) break;
+        if (lnew > l1) break;
+        if (isnan(lnew) || isinf(lnew)) break;
+        lroot = lnew;
+        if ((double)r_eps < 1e-5 || iteration > 100) break;
+        iteration++;
+    }
+    return lroot;
+}
+
 template <int C>
 // two waves per SIMD: a lone wave cannot issue fp64 VALU at the pipe's rate (measured 2.3x faster at 2 than at 1;
 // <= 256 VGPRs at c <= 6 with a handful of spills outside the hot loops); larger c keeps one wave and its registers
@@ -674,30 +703,10 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
                 },
                 (double)l0, (double)l1, (double)f0, (double)f1);
             // newton (pyx:1349-1416), all f32
-            float lroot = (float)root;
-            {
-                int iteration = 0;
-                for (;;) {
-                    EvalOut e;
-                    eval_specific<C, true>(pr, xrow, lroot, lane, own, e);
-                    n_full++;
-                    const float d1 = d1_f(pr, lroot, e.yPy, e.yPPy, e.trP);
-                    const float d2 = d2_f(pr, lroot, e.yPy, e.yPPy, e.yPPPy, e.trP, e.trPP);
-                    const float ratio = __fdiv_rn(d1, d2);
-                    // np.sign(ratio)*np.sign(d1)*np.sign(d2) <= 0.0   (NaN compares False)
-                    const bool any_nan = (ratio != ratio) || (d1 != d1) || (d2 != d2);
-                    const float sr = (float)((ratio > 0) - (ratio < 0)), s1 = (float)((d1 > 0) - (d1 < 0)), s2 = (float)((d2 > 0) - (d2 < 0));
-                    if (!any_nan && sr * s1 * s2 <= 0.0f) break;
-                    const float lnew = __fsub_rn(lroot, ratio);
-                    const float r_eps = (float)(fabs((double)__fsub_rn(lnew, lroot)) / fabs((double)lroot));
-                    if (lnew < l0) break;
-                    if (lnew > l1) break;
-                    if (isnan(lnew) || isinf(lnew)) break;
-                    lroot = lnew;
-                    if ((double)r_eps < 1e-5 || iteration > 100) break;
-                    iteration++;
-                }
-            }
+            const float lroot = newton_dev(pr, (float)root, l0, l1, [&](float lf, EvalOut &e) {
+                eval_specific<C, true>(pr, xrow, lf, lane, own, e);
+                n_full++;
+            });
             EvalOut e;
             eval_specific<C, false>(pr, xrow, lroot, lane, own, e);   // pyx:186
             n_fast++;
@@ -791,6 +800,179 @@ __global__ __launch_bounds__(256) void transpose_kernel(long long n, long long p
         long long g = g0 + r, i = i0 + tx;
         if (g < p && i < ldx) Xr[(size_t)g * ldx + i] = tile[tx][r];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inspection surface (the functions tests/test_pygemma.py:256-294 calls directly): precompute_mat (pyx:880) with
+// every level exported, the *_overload scalars, newton.  One wavefront, any m = ctot+1 <= PG_MAX_COVARIATES + 2,
+// written for checking, not for speed: level-0 Gram entries one at a time with exactly the arithmetic of
+// gram_pass (per-lane fma chain over i = lane, lane+64, .., xor butterfly 1..32), then the sweeps run serially.
+constexpr int IM = PG_MAX_COVARIATES + 2;
+
+struct InspectParams {
+    AssocParams pr;          // n, nu = n - ctot, logl_c, fixed = d (rowf = 1), the pairwise-sum plan
+    int ctot, m, full;
+    float lam, lam_min, lam_max;
+    const float *d, *Wx, *y; // Wx: n x ctot row-major (the reference's np.c_[W, x]); y: n
+    float *P3, *Q3, *R3;     // [m][m][m] indexed [row][level][col]; undefined entries NaN
+    float *vecs;             // [5][m]: yt_Pi_y, yt_Pi_Pi_y, yt_Pi_Pi_Pi_y, tr_Pi, tr_Pi_Pi per level
+    float *scal;             // logdet_Wt_H_inv_W, logdet_H, d1, d2 (full only), logL at the last level
+    float *out;              // newton: the root
+};
+
+__device__ __forceinline__ float inspect_col(const InspectParams &ip, int j, int i)
+{
+    return (j < ip.ctot) ? ip.Wx[(size_t)i * ip.ctot + j] : ip.y[i];
+}
+
+// level-0 Grams into G[3][IM][IM] (lower triangles) + traces; all lanes hold the same values afterwards
+__device__ void inspect_gram0(const InspectParams &ip, float lam, bool full, int lane, double (*G)[IM][IM], double *tr)
+{
+    const int n = ip.pr.n, m = ip.m;
+    for (int j = 0; j < m; j++)
+        for (int k = 0; k <= j; k++) {
+            double P = 0.0, Q = 0.0, R = 0.0;
+            for (int i = lane; i < n; i += 64) {
+                const double hd = (double)hinv_f32(lam, ip.d[i]);
+                const double cj = (double)inspect_col(ip, j, i), ck = (double)inspect_col(ip, k, i);
+                const double aj = hd * cj, ak = hd * ck;
+                P = fma(aj, ck, P);
+                Q = fma(aj, ak, Q);
+                if (full) { const double gj = (hd * hd) * cj; R = fma(gj, ak, R); }
+            }
+            P = bfly(P); Q = bfly(Q); R = bfly(R);
+            if (lane == 0) { G[0][j][k] = P; G[1][j][k] = Q; G[2][j][k] = full ? R : 0.0; }
+        }
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const double hd = (double)hinv_f32(lam, ip.d[i]);
+        s1 += hd;
+        s2 = fma(hd, hd, s2);
+    }
+    s1 = bfly(s1); s2 = bfly(s2);
+    if (lane == 0) { tr[0] = s1; tr[1] = full ? s2 : 0.0; }
+    wave_lds_sync();
+}
+
+// the c_tot sweeps (pyx:947-963 / :1007-1036) on lane 0, statement for statement the oracle's sweeps(order=1);
+// exp: optional export of every level.  Returns the last level's forms in o.
+__device__ void inspect_sweeps(const InspectParams &ip, bool full, double (*G)[IM][IM], const double *tr, bool exp, EvalOut &o)
+{
+    const int m = ip.m;
+    double (*P)[IM] = G[0], (*Q)[IM] = G[1], (*R)[IM] = G[2];
+    double trP = tr[0], trPP = tr[1];
+    float ld = 0.0f;
+    P[0][0] = dmaxf(P[0][0], PG_MINV);
+    auto level_out = [&](int lv) {
+        if (!exp) return;
+        for (int r = lv; r < m; r++)
+            for (int c = lv; c <= r; c++) {
+                const size_t idx = ((size_t)r * m + lv) * m + c;
+                ip.P3[idx] = (float)P[r][c]; ip.Q3[idx] = (float)Q[r][c];
+                if (full) ip.R3[idx] = (float)R[r][c];
+            }
+        ip.vecs[0 * m + lv] = (float)P[m - 1][m - 1];
+        ip.vecs[1 * m + lv] = (float)Q[m - 1][m - 1];
+        if (full) ip.vecs[2 * m + lv] = (float)R[m - 1][m - 1];
+        ip.vecs[3 * m + lv] = (float)trP;
+        ip.vecs[4 * m + lv] = (float)trPP;
+    };
+    level_out(0);
+    for (int i = 1; i < m; i++) {
+        const int q = i - 1;
+        const double a = P[q][q], b = Q[q][q], e = R[q][q];
+        double u[IM], v[IM], w[IM];
+        for (int r = i; r < m; r++) { u[r] = P[r][q]; v[r] = Q[r][q]; w[r] = R[r][q]; }
+        if (full) {
+            const double ba = b / a;
+            trPP = trPP + ba * ba - 2 * (e / a);
+            const double a2 = a * a, a3 = a2 * a, b2 = b * b;
+            const double cR = (e / a2) - (b2 / a3), ia = -1.0 / a, ba2 = b / a2;
+            for (int r = i; r < m; r++)
+                for (int c = i; c <= r; c++) {
+                    const double t1 = fma(cR * u[c], u[r], R[r][c]);
+                    double t2 = fma(ia * u[c], w[r], 0.0); t2 = fma(ia * w[c], u[r], t2);
+                    const double t3 = fma(ia * v[c], v[r], 0.0);
+                    double t4 = fma(ba2 * u[c], v[r], 0.0); t4 = fma(ba2 * v[c], u[r], t4);
+                    R[r][c] = ((t1 + t2) + t3) + t4;
+                }
+            R[i][i] = dmaxf(R[i][i], PG_MINV);
+        }
+        trP = trP - b / a;
+        {
+            const double a2 = a * a, al1 = b / a2, ia = -1.0 / a;
+            for (int r = i; r < m; r++)
+                for (int c = i; c <= r; c++) {
+                    const double t1 = fma(al1 * u[c], u[r], Q[r][c]);
+                    double t2 = fma(ia * u[c], v[r], 0.0); t2 = fma(ia * v[c], u[r], t2);
+                    Q[r][c] = t1 + t2;
+                }
+            Q[i][i] = dmaxf(Q[i][i], PG_MINV);
+        }
+        ld = (float)((double)ld + log(a));
+        {
+            const double ia = -1.0 / a;
+            for (int r = i; r < m; r++)
+                for (int c = i; c <= r; c++) P[r][c] = fma(ia * u[c], u[r], P[r][c]);
+            P[i][i] = dmaxf(P[i][i], PG_MINV);
+        }
+        if (!full) trPP = 0.0;
+        level_out(i);
+    }
+    o.yPy = (float)P[m - 1][m - 1]; o.yPPy = (float)Q[m - 1][m - 1]; o.yPPPy = (float)R[m - 1][m - 1];
+    o.trP = (float)trP; o.trPP = (float)trPP; o.ld = ld;
+    o.Pxx_c = (m >= 2) ? (float)P[m - 2][m - 2] : 0.0f; o.Pyx_c = (m >= 2) ? (float)P[m - 1][m - 2] : 0.0f;
+}
+
+__global__ __launch_bounds__(64) void precompute_kernel(InspectParams ip)
+{
+    __shared__ double G[3][IM][IM];
+    __shared__ double tr[2];
+    __shared__ EvalOut eo;
+    extern __shared__ float vals_dyn[];
+    const int lane = threadIdx.x, m = ip.m;
+    for (int idx = lane; idx < m * m * m; idx += 64) { ip.P3[idx] = NAN; ip.Q3[idx] = NAN; ip.R3[idx] = NAN; }
+    for (int idx = lane; idx < 5 * m; idx += 64) ip.vecs[idx] = NAN;
+    for (int idx = lane; idx < 3 * IM * IM; idx += 64) (&G[0][0][0])[idx] = 0.0;
+    wave_lds_sync();
+    inspect_gram0(ip, ip.lam, ip.full != 0, lane, G, tr);
+    if (lane == 0) inspect_sweeps(ip, ip.full != 0, G, tr, true, eo);
+    wave_lds_sync();
+    const float ldH = device_logdet_H(ip.pr, ip.lam, lane, vals_dyn);
+    if (lane == 0) {
+        ip.scal[0] = eo.ld; ip.scal[1] = ldH;
+        ip.scal[2] = d1_f(ip.pr, ip.lam, eo.yPy, eo.yPPy, eo.trP);
+        ip.scal[3] = ip.full ? d2_f(ip.pr, ip.lam, eo.yPy, eo.yPPy, eo.yPPPy, eo.trP, eo.trPP) : NAN;
+        ip.scal[4] = logl_f(ip.pr, eo.yPy, ldH, eo.ld);
+    }
+}
+
+__global__ __launch_bounds__(64) void newton_kernel(InspectParams ip)
+{
+    __shared__ double G[3][IM][IM];
+    __shared__ double tr[2];
+    __shared__ EvalOut eo;
+    const int lane = threadIdx.x;
+    const float root = newton_dev(ip.pr, ip.lam, ip.lam_min, ip.lam_max, [&](float lf, EvalOut &e) {
+        for (int idx = lane; idx < 3 * IM * IM; idx += 64) (&G[0][0][0])[idx] = 0.0;
+        wave_lds_sync();
+        inspect_gram0(ip, lf, true, lane, G, tr);
+        if (lane == 0) inspect_sweeps(ip, true, G, tr, false, eo);
+        wave_lds_sync();
+        e = eo;
+        wave_lds_sync();
+    });
+    if (lane == 0) ip.out[0] = root;
+}
+
+// the three *_overload scalars on caller-supplied quadratic forms (pyx:1813, :1656, :1675); args: lam, yPy, yPPy, yPPPy,
+// trP, trPP, logdet_H, logdet_Wt_H_inv_W
+__global__ void reml_scalars_kernel(AssocParams pr, const float *a, float *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    out[0] = logl_f(pr, a[1], a[6], a[7]);
+    out[1] = d1_f(pr, a[0], a[1], a[2], a[4]);
+    out[2] = d2_f(pr, a[0], a[1], a[2], a[3], a[4], a[5]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -903,5 +1085,75 @@ extern "C" int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const floa
     }
     if (rc) return rc;
     if (pval) return pg_fdist_sf_dev(ctx, p, F, (double)(n - c - 1), pval);
+    return PG_OK;
+}
+
+// ---- inspection surface ----------------------------------------------------------------------------------------------
+static int inspect_params(pg_ctx *ctx, int64_t n, int ctot, InspectParams &ip, const float *d)
+{
+    PG_REQUIRE(n >= 2 && n < (1LL << 30), "inspect: bad n");
+    if (ctot < 1 || ctot > PG_MAX_COVARIATES + 1) {
+        set_error("inspect: %d columns not supported by this build (1..%d)", ctot, PG_MAX_COVARIATES + 1);
+        return PG_ENOTSUP;
+    }
+    PG_REQUIRE(n - ctot > 0, "inspect: n - c must be positive");
+    PG_HIP(hipSetDevice(ctx->device));
+    int rc = build_npsum_plan(ctx, n);
+    if (rc) return rc;
+    AssocParams &pr = ip.pr;
+    pr.n = (int)n; pr.npad = (int)((n + 63) / 64 * 64); pr.c = ctot - 1; pr.niter = pr.npad / 64;
+    pr.nu = (int)(n - ctot); pr.rowf = 1; pr.fixed = d;
+    {
+        float r = (float)((0.5 * (double)(n - ctot)) * std::log(0.5 * (double)(n - ctot) / M_PI));  // pyx:1821
+        r = (float)((double)r - (0.5 * (double)(n - ctot)));                                          // pyx:1822
+        pr.logl_c = r;
+    }
+    pr.leaf = ctx->plan.d_leaf; pr.node = ctx->plan.d_node; pr.level = ctx->plan.d_level; pr.chunk = ctx->plan.d_chunk;
+    pr.n_leaf = ctx->plan.n_leaf; pr.n_level = ctx->plan.n_level; pr.n_chunk = ctx->plan.n_chunk;
+    pr.n_vals = ctx->plan.n_leaf + ctx->plan.n_node;
+    ip.ctot = ctot; ip.m = ctot + 1; ip.d = d;
+    return PG_OK;
+}
+
+extern "C" int pg_precompute_mat_dev(pg_ctx *ctx, int64_t n, int ctot, float lam, const float *d, const float *Wx, const float *y,
+                                     int full, float *P3, float *Q3, float *R3, float *vecs, float *scal)
+{
+    PG_REQUIRE(ctx && d && Wx && y && P3 && Q3 && R3 && vecs && scal, "pg_precompute_mat_dev: NULL argument");
+    InspectParams ip{};
+    int rc = inspect_params(ctx, n, ctot, ip, d);
+    if (rc) return rc;
+    ip.full = full ? 1 : 0; ip.lam = lam; ip.Wx = Wx; ip.y = y;
+    ip.P3 = P3; ip.Q3 = Q3; ip.R3 = R3; ip.vecs = vecs; ip.scal = scal;
+    precompute_kernel<<<1, 64, (size_t)ip.pr.n_vals * 4 + 16, ctx->stream>>>(ip);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+extern "C" int pg_newton_dev(pg_ctx *ctx, int64_t n, int ctot, float lam, float lam_min, float lam_max, const float *d,
+                             const float *Wx, const float *y, float *root)
+{
+    PG_REQUIRE(ctx && d && Wx && y && root, "pg_newton_dev: NULL argument");
+    InspectParams ip{};
+    int rc = inspect_params(ctx, n, ctot, ip, d);
+    if (rc) return rc;
+    ip.full = 1; ip.lam = lam; ip.lam_min = lam_min; ip.lam_max = lam_max; ip.Wx = Wx; ip.y = y; ip.out = root;
+    newton_kernel<<<1, 64, 0, ctx->stream>>>(ip);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+extern "C" int pg_reml_scalars_dev(pg_ctx *ctx, int64_t n, int ctot, const float *args8, float *out3)
+{
+    PG_REQUIRE(ctx && args8 && out3 && n - ctot > 0, "pg_reml_scalars_dev: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    AssocParams pr{};
+    pr.n = (int)n; pr.nu = (int)(n - ctot);
+    {
+        float r = (float)((0.5 * (double)(n - ctot)) * std::log(0.5 * (double)(n - ctot) / M_PI));
+        r = (float)((double)r - (0.5 * (double)(n - ctot)));
+        pr.logl_c = r;
+    }
+    reml_scalars_kernel<<<1, 1, 0, ctx->stream>>>(pr, args8, out3);
+    PG_HIP(hipGetLastError());
     return PG_OK;
 }

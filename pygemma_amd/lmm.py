@@ -21,8 +21,10 @@ import numpy as np
 import pandas as pd
 
 from . import _lib
+from .model import *          # noqa: F401,F403  (precompute_mat, calc_lambda_restricted, newton, the *_overload scalars)
+from . import model as _model
 
-__all__ = ["pygemma", "SampleIter"]
+__all__ = ["pygemma", "SampleIter"] + _model.__all__
 
 _BATCH_BYTES = 6 << 30   # device bytes for one SNP batch (raw block + rotated block)
 
