@@ -187,23 +187,27 @@ struct GenoParams {
 // read address, so the 16 rows a ds_read_b128 lane group touches fall on 16 different bank quads.
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-// Staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of FOUR U-plane
-// buffers (128 rows; stage t = plane t&1 of K-tile t>>1 lives in ring[t&3]) and two genotype buffers (256 rows), with the
-// DMA of stage t+2 in flight across the barriers of stage t.  Waits are counted (`s_waitcnt vmcnt(#issued this stage)`
-// retires everything older) and the barriers are raw s_barrier: __syncthreads() would drain the DMA at every barrier.
+// Staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of THREE U-plane
+// buffers (128 rows; stage t = plane t&1 of K-tile t>>1 lives in B[t%3]) and THREE genotype buffers (256 rows; K-tile T in
+// A[T%3]), with the DMA of stage t+2 / of K-tile T+2 in flight across the barriers of stage t.  Waits are counted
+// (`s_waitcnt vmcnt(#issued this stage)` retires everything older) and the barriers are raw s_barrier: __syncthreads()
+// would drain the DMA at every barrier.  Every stage issues the same four DMA instructions per wave (two for the U plane
+// two stages ahead, two for half of the wave's share of the genotype tile two K-tiles ahead): a stage that issues more
+// than its MFMA phase can cover stalls both waves of the SIMD at the next barrier (measured on the 2-buffer version:
+// 2+6 instructions per K-tile cost 3x what 2+2 or 0+4 cost).
 //
 // Ping-pong: waves 0-3 ("early") and 4-7 ("late") sit one per SIMD and run half a stage apart, so that while one wave of
 // a SIMD issues its 32 MFMAs the other issues its DMA and reads its fragments:
 //   phase 2t   : early mem(t)   | late mfma(t-1)
 //   phase 2t+1 : early mfma(t)  | late mem(t)          (one s_barrier between consecutive phases)
-// mem(t) = issue DMA(t+2) [+ the genotype tile two K-tiles ahead, at plane 1], read the fragments of stage t into
-// registers, wait until the own share of everything issued before this stage has landed.  ring[(t+2)&3] was last read in
-// mem(t-2); the genotype fragments live in registers for both planes of a K-tile, and genotype buffer T&1 (read only at
-// plane 0 of tile T) is refilled with tile T+2 from plane 1 of tile T on.
+// mem(t) = issue DMA, read the fragments of stage t into registers, wait until the own share of everything issued before
+// this stage has landed.  B[(t+2)%3] was last read in mem(t-1) (a barrier ago); A[(T+2)%3] at plane 0 of K-tile T-1.
+// The genotype fragments live in registers for both planes of a K-tile.
 __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 128 * 128 + 2 * 256 * 128];
-    unsigned char *const Bs = lds, *const As = lds + 4 * 128 * 128;
+    constexpr int BBUF = 128 * 128, ABUF = 256 * 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * BBUF + 3 * ABUF];
+    unsigned char *const Bs = lds, *const As = lds + 3 * BBUF;
     const int T = gp.tiles_m * gp.tiles_n;
     const int b = blockIdx.x;
     const int q = T / 8, r = T % 8, xcd = b % 8;
@@ -243,40 +247,43 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
         rn = rn < gp.n ? rn : gp.n - 1;
         gB[t] = reinterpret_cast<const unsigned char *>(gp.Up + rn * gp.ldp) + swz(row, lchunk) * 16;
     }
-    auto dmaB = [&](int stage) {
-        unsigned char *dst = Bs + (stage & 3) * (128 * 128) + (wave * 16) * 128;
+    auto dmaB = [&](int stage, int buf) {
+        unsigned char *dst = Bs + buf * BBUF + (wave * 16) * 128;
 #pragma unroll
         for (int t = 0; t < 2; t++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gB[t] + (size_t)stage * GBK * 2),
                                              (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
     };
-    auto dmaA = [&](int ktile) {
-        unsigned char *dst = As + (ktile & 1) * (256 * 128) + (wave * 32) * 128;
+    auto dmaA = [&](int ktile, int buf, int half) {       // rows 16*half .. 16*half+15 of this wave's 32 rows
+        unsigned char *dst = As + buf * ABUF + (wave * 32 + 16 * half) * 128;
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gA[t] + (size_t)ktile * GBK * 2),
+        for (int t = 0; t < 2; t++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gA[2 * half + t] + (size_t)ktile * GBK * 2),
                                              (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
     };
     // prologue: K-tile 0 (genotypes + both planes = stages 0, 1) and the genotypes of K-tile 1; only stage 0's operands
     // have to have landed at the first barrier
-    dmaA(0); dmaB(0);
-    dmaB(1);
-    if (gp.KT > 1) { dmaA(1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    dmaA(0, 0, 0); dmaA(0, 0, 1); dmaB(0, 0);
+    dmaB(1, 1);
+    if (gp.KT > 1) { dmaA(1, 1, 0); dmaA(1, 1, 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const bool late = wave >= 4;
     if (late) __builtin_amdgcn_s_barrier();
-    halfx8 fa[2][4];   // genotype fragments: read at plane 0 of a K-tile, reused for its second U plane
+    int a0 = 0, b0 = 0;   // buffers of the current K-tile / stage: T % 3, t % 3
+    halfx8 fa[2][4];      // genotype fragments: read at plane 0 of a K-tile, reused for its second U plane
     for (int ktile = 0; ktile < gp.KT; ktile++) {
-      const unsigned char *Apar = As + (ktile & 1) * (256 * 128), *Bpar = Bs + (ktile & 1) * (2 * 128 * 128);
+      const unsigned char *Acur = As + a0 * ABUF;
+      const int a2 = (a0 >= 1) ? a0 - 1 : 2;              // (T + 2) % 3
 #pragma unroll
       for (int pl = 0; pl < 2; pl++) {
         const int kt = 2 * ktile + pl;
-        const unsigned char *Bcur = Bpar + pl * (128 * 128);
+        const unsigned char *Bcur = Bs + b0 * BBUF;
+        const int b2 = (b0 >= 1) ? b0 - 1 : 2;            // (t + 2) % 3
         int issued = 0;
         if (kt + 2 < KT2) {
-            dmaB(kt + 2); issued = 2;
-            if (pl == 1 && ktile + 2 < gp.KT) { dmaA(ktile + 2); issued = 6; }
+            dmaB(kt + 2, b2); issued = 2;
+            if (ktile + 2 < gp.KT) { dmaA(ktile + 2, a2, pl); issued = 4; }
         }
         // 16x16x32 operand: lane l holds row (l & 15), k = 32*ks + 8*(l >> 4) .. +7 = logical 16-byte chunk 4*ks + (l >> 4)
         halfx8 fb[2][4];
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int row = wm * 64 + i * 16 + (lane & 15);
-                    fa[ks][i] = *reinterpret_cast<const halfx8 *>(Apar + row * 128 + swz(row, chunk) * 16);
+                    fa[ks][i] = *reinterpret_cast<const halfx8 *>(Acur + row * 128 + swz(row, chunk) * 16);
                 }
             }
 #pragma unroll
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
                 fb[ks][j] = *reinterpret_cast<const halfx8 *>(Bcur + row * 128 + swz(row, chunk) * 16);
             }
         }
-        if (issued == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (issued == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -314,7 +321,9 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        b0 = (b0 == 2) ? 0 : b0 + 1;
       }
+      a0 = (a0 == 2) ? 0 : a0 + 1;
     }
     if (!late) __builtin_amdgcn_s_barrier();
     // epilogue: Xr[g][k] = v0_g * (U'1)_k + (dx_g / S) * acc   (fp64 combine, one rounding to fp32); pad columns zero
