@@ -104,7 +104,9 @@ int pg_rotate_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU
  * values: hard calls 0/1/2, raw or centred/standardised).  U'x = v0 (U'1) + dx (U'code): the codes are exact in fp16,
  * U (scaled by a power of two) is split once into two fp16 planes (residual <= 2^-24 |U|, the size of float32's own
  * rounding of U), the products are exact in fp32 and accumulate in fp32 on the fp16 MFMA pipe
- * (same error class as pg_rotate_dev / the reference's sgemm, 8x fewer matrix cycles).
+ * (same error class as pg_rotate_dev / the reference's sgemm, 8x fewer matrix cycles).  A column may also hold ONE other
+ * value anywhere (missing calls imputed with the column mean, experiments/benchmarks/benchmarks.py:243-244): such blocks
+ * take a second, accumulating pass on the 0/1 indicator plane.
  *   pg_geno_prep_dev   : once per U -> Uprep (pg_geno_prep_bytes(n) bytes, device)
  *   pg_rotate_geno_dev : per SNP block; *is_geno = 1 and Xr written (same layout as pg_rotate_dev) when every column
  *                        qualifies, else *is_geno = 0 and Xr untouched (call pg_rotate_dev).  Synchronises the stream. */

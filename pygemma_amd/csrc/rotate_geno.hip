@@ -4,6 +4,11 @@
 //
 //   x_g = v0_g + dx_g * code_g,  code in {0,1,2}   =>   U'x_g = v0_g * (U'1) + dx_g * (U' code_g)
 //
+// A column may in addition hold ONE other value o_g anywhere (missing calls imputed with the column mean — what the
+// reference's callers do before lmm.pygemma, experiments/benchmarks/benchmarks.py:243-244):
+//   x_g = v0_g + dx_g * code_g + (o_g - v0_g) * ind_g   (code 0 where ind = 1)
+// and the block takes a second pass of the same GEMM on the 0/1 indicator plane, accumulated onto the first.
+//
 // The codes are exact in fp16, so U' code needs only U split into two fp16 planes, S*U = H1 + H2 + e with S the power of two that puts S*max|U| in [2^14, 2^15)
 // (keeps H2 out of the fp16 subnormals) and round-to-nearest at both steps: |e| <= 2^-24 |S*U| — the size of fp32's own
 // quantisation of U (measured: the split adds 0.6x the error U already carries from its rounding to fp32, and 1/20 of
@@ -112,10 +117,11 @@ __global__ void colsum_reduce_kernel(long long n, int kt, double *colsum)
 __device__ __forceinline__ int f2key(float f) { int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float key2f(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
 
-__global__ void minmax_init_kernel(long long p, int *kmin, int *kmax)
+constexpr int OTHER_EMPTY = 0x7FC00001;   // a NaN payload: never a data value (NaNs disqualify the block)
+__global__ void minmax_init_kernel(long long p, int *kmin, int *kmax, int *other)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < p) { kmin[g] = 0x7FFFFFFF; kmax[g] = (int)0x80000000; }
+    if (g < p) { kmin[g] = 0x7FFFFFFF; kmax[g] = (int)0x80000000; other[g] = OTHER_EMPTY; }
 }
 __global__ __launch_bounds__(256) void minmax_geno_kernel(long long n, long long p, const float *X, long long ldX, int *kmin, int *kmax, int *flag)
 {
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) void minmax_geno_kernel(long long n, long long
     atomicMax(&kmax[g], hi);
 }
 __global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long p, const float *X, long long ldX, const int *kmin, const int *kmax,
-                                                          unsigned short *Gt, long long ldk, int *flag)
+                                                          int *other, unsigned short *Gt, long long ldk, int *flag)
 {
     __shared__ unsigned short tile[32][34];
     const long long g0 = (long long)blockIdx.x * 32, i0 = (long long)blockIdx.y * 32;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long
     const long long g = g0 + tx;
     const float lo = (g < p) ? key2f(kmin[g]) : 0.0f, hv = (g < p) ? key2f(kmax[g]) : 0.0f;
     const float mid = lo + 0.5f * (hv - lo), tol = 8.0f * 1.1920929e-7f * fmaxf(fabsf(lo), fabsf(hv));
-    bool bad = false;
+    bool bad = false, any_ind = false;
     for (int r = ty; r < 32; r += 8) {
         const long long i = i0 + r;
         unsigned short code = 0;
@@ -152,29 +158,56 @@ __global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long
             const float x = X[i * ldX + g];
             if (x == lo) code = 0;
             else if (x == hv) code = 0x4000;                       // fp16 2.0
-            else { code = 0x3C00; if (!(fabsf(x - mid) <= tol)) bad = true; }   // fp16 1.0
+            else if (fabsf(x - mid) <= tol) code = 0x3C00;         // fp16 1.0
+            else {                                                 // the column's one other value (every occurrence the same bits)
+                const int xb = __float_as_int(x);
+                const int prev = atomicCAS(&other[g], OTHER_EMPTY, xb);
+                if (prev != OTHER_EMPTY && prev != xb) bad = true;
+                any_ind = true;
+            }
         }
         tile[r][tx] = code;
     }
     if (bad) atomicOr(flag, 1);
+    if (any_ind) atomicOr(flag + 1, 1);
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const long long gg = g0 + r, i = i0 + tx;
         if (gg < p && i < ldk) Gt[gg * ldk + i] = tile[tx][r];
     }
 }
-__global__ void params_geno_kernel(long long p, const int *kmin, const int *kmax, float *v0, float *dx)
+// indicator plane (fp16 0/1) of the columns' other value, SNP-major like Gt; only run for blocks that have one
+__global__ __launch_bounds__(256) void indicator_geno_kernel(long long n, long long p, const float *X, long long ldX, const int *other,
+                                                             unsigned short *Gi, long long ldk)
+{
+    __shared__ unsigned short tile[32][34];
+    const long long g0 = (long long)blockIdx.x * 32, i0 = (long long)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long long g = g0 + tx;
+    const int ob = (g < p) ? other[g] : OTHER_EMPTY;
+    for (int r = ty; r < 32; r += 8) {
+        const long long i = i0 + r;
+        tile[r][tx] = (i < n && g < p && ob != OTHER_EMPTY && __float_as_int(X[i * ldX + g]) == ob) ? 0x3C00 : 0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long long gg = g0 + r, i = i0 + tx;
+        if (gg < p && i < ldk) Gi[gg * ldk + i] = tile[tx][r];
+    }
+}
+__global__ void params_geno_kernel(long long p, const int *kmin, const int *kmax, const int *other, float *v0, float *dx, float *dlt)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= p) return;
     const float lo = key2f(kmin[g]), hv = key2f(kmax[g]);
     v0[g] = lo; dx[g] = 0.5f * (hv - lo);
+    dlt[g] = (other[g] == OTHER_EMPTY) ? 0.0f : __int_as_float(other[g]) - lo;   // exact or one rounding: folded in fp64 below
 }
 
 struct GenoParams {
     long long n, p, ldx, ldk, ldp;
     const unsigned short *Gt, *Up;
-    const float *v0, *dx;
+    const float *v0, *dx;       // v0 == nullptr: the accumulate pass (Xr += dx * acc)
     const double *colsum;
     float *Xr;
     int tiles_m, tiles_n, KT;   // KT = K-tiles of 64 samples; stages = 2*KT (two U planes per K-tile)
@@ -326,8 +359,10 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
       a0 = (a0 == 2) ? 0 : a0 + 1;
     }
     if (!late) __builtin_amdgcn_s_barrier();
-    // epilogue: Xr[g][k] = v0_g * (U'1)_k + (dx_g / S) * acc   (fp64 combine, one rounding to fp32); pad columns zero
+    // epilogue: Xr[g][k] = v0_g * (U'1)_k + (dx_g / S) * acc   (fp64 combine, one rounding to fp32); pad columns zero.
+    // Accumulate pass (v0 == nullptr): Xr[g][k] += (dx_g / S) * acc.
     const double invS = (double)gp.scale[1];
+    const bool accum = gp.v0 == nullptr;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -338,8 +373,10 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
             for (int e = 0; e < 4; e++) {
                 const long long row = m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + e;
                 if (row < gp.p && col < gp.ldx) {
-                    const double v = (col < gp.n) ? fma((double)gp.dx[row] * invS, (double)acc[i][j][e], (double)gp.v0[row] * ck) : 0.0;
-                    gp.Xr[row * gp.ldx + col] = (float)v;
+                    float *dst = gp.Xr + row * gp.ldx + col;
+                    const double base = accum ? (double)(*dst) : (double)gp.v0[row] * ck;
+                    const double v = (col < gp.n) ? fma((double)gp.dx[row] * invS, (double)acc[i][j][e], base) : 0.0;
+                    *dst = (float)v;
                 }
             }
         }
@@ -380,7 +417,7 @@ extern "C" int pg_geno_prep_dev(pg_ctx *ctx, int64_t n, const float *U, int64_t 
 extern "C" size_t pg_geno_work_bytes(int64_t n, int64_t p)
 {
     const long long ldk = (n + GBK - 1) / GBK * GBK;
-    return (((size_t)p * ldk * 2 + 255) & ~(size_t)255) + (size_t)p * 16 + 512;
+    return 2 * (((size_t)p * ldk * 2 + 255) & ~(size_t)255) + (size_t)p * 24 + 512;   // codes, indicator plane, v0/dx/delta/min/max/other
 }
 extern "C" int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const float *X, int64_t ldX, float *Xr, int64_t ldx,
                                   void *work, int *is_geno_host)
@@ -389,22 +426,23 @@ extern "C" int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void 
     PG_REQUIRE(n > 0 && p > 0 && ldX >= p && ldx >= n && ldx <= (n + 127) / 128 * 128, "pg_rotate_geno_dev: bad shape");
     PG_HIP(hipSetDevice(ctx->device));
     const long long kt = (n + GBK - 1) / GBK, ldk = kt * GBK, ldp = kt * 2 * GBK;
-    unsigned short *Gt = (unsigned short *)work;
-    char *tail = (char *)work + (((size_t)p * ldk * 2 + 255) & ~(size_t)255);
-    float *v0 = (float *)tail, *dx = v0 + p;
-    int *kmin = (int *)(dx + p), *kmax = kmin + p;
-    int *flag = kmax + p;
-    PG_HIP(hipMemsetAsync(flag, 0, 4, ctx->stream));
-    minmax_init_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax);
+    const size_t plane = ((size_t)p * ldk * 2 + 255) & ~(size_t)255;
+    unsigned short *Gt = (unsigned short *)work, *Gi = (unsigned short *)((char *)work + plane);
+    char *tail = (char *)work + 2 * plane;
+    float *v0 = (float *)tail, *dx = v0 + p, *dlt = dx + p;
+    int *kmin = (int *)(dlt + p), *kmax = kmin + p, *other = kmax + p;
+    int *flag = other + p;           // flag[0]: not a genotype block; flag[1]: some column holds an other (imputed) value
+    PG_HIP(hipMemsetAsync(flag, 0, 8, ctx->stream));
+    minmax_init_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, other);
     minmax_geno_kernel<<<dim3((unsigned)((p + 63) / 64), (unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, flag);
-    encode_geno_kernel<<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, Gt, ldk, flag);
-    params_geno_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, v0, dx);
+    encode_geno_kernel<<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk, flag);
+    params_geno_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, other, v0, dx, dlt);
     PG_HIP(hipGetLastError());
-    int hflag = 0;
-    PG_HIP(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    int hflag[2] = {0, 0};
+    PG_HIP(hipMemcpyAsync(hflag, flag, 8, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
-    *is_geno_host = hflag ? 0 : 1;
-    if (hflag) return PG_OK;
+    *is_geno_host = hflag[0] ? 0 : 1;
+    if (hflag[0]) return PG_OK;
     GenoParams gp{};
     gp.n = n; gp.p = p; gp.ldx = ldx; gp.ldk = ldk; gp.ldp = ldp;
     gp.Gt = Gt; gp.Up = (const unsigned short *)Uprep;
@@ -416,6 +454,11 @@ extern "C" int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void 
     const long long T = (long long)gp.tiles_m * gp.tiles_n;
     PG_REQUIRE(T < (1LL << 31), "pg_rotate_geno_dev: too many tiles");
     rotate_geno_kernel<<<dim3((unsigned)T), 512, 0, ctx->stream>>>(gp);
+    if (hflag[1]) {   // second pass on the indicator plane: Xr += (other - v0) * U'ind
+        indicator_geno_kernel<<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk);
+        gp.Gt = Gi; gp.v0 = nullptr; gp.dx = dlt;
+        rotate_geno_kernel<<<dim3((unsigned)T), 512, 0, ctx->stream>>>(gp);
+    }
     PG_HIP(hipGetLastError());
     return PG_OK;
 }

@@ -67,8 +67,35 @@ def test_rotate_genotype_rejects_non_genotype_block(ctx):
     n, p = 128, 64
     U = np.linalg.qr(rng.standard_normal((n, n)))[0].astype(np.float32)
     X = _geno(rng, n, p, True)
-    X[5, 7] += 0.125                        # a fourth value in one column (an imputed dosage)
+    X[5, 7] += 0.125; X[9, 7] -= 0.0625     # a fourth AND a fifth value in one column (imputed dosages)
     got, ok = ops.rotate_geno(U, X, ctx=ctx)
     assert not ok and got is None
     X = _geno(rng, n, p, True); X[3, 3] = np.nan
     assert ops.rotate_geno(U, X, ctx=ctx)[1] is False
+
+
+@pytest.mark.parametrize("n,p,std", [(300, 200, False), (1000, 513, True)])
+def test_rotate_genotype_with_mean_imputed_missing(n, p, std, ctx):
+    """Columns whose missing calls were imputed with the column mean (one extra value per column, what the reference's
+    callers feed: experiments/benchmarks/benchmarks.py:243-244) stay on the genotype path: codes + indicator pass."""
+    from pygemma_amd import ops
+    rng = np.random.default_rng(n)
+    U = np.linalg.qr(rng.standard_normal((n, n)))[0].astype(np.float32)
+    G = rng.binomial(2, rng.uniform(0.05, 0.5, p), size=(n, p)).astype(np.float64)
+    miss = rng.random((n, p)) < 0.02
+    miss[:, ::7] = False                    # some columns without missing calls
+    G[miss] = np.nan
+    mu = np.nanmean(G, axis=0)
+    G = np.where(np.isnan(G), mu[None, :], G)
+    if std:
+        G = (G - G.mean(0)) / np.maximum(G.std(0), 1e-9)
+    X = G.astype(np.float32)
+    got, ok = ops.rotate_geno(U, X, ctx=ctx)
+    assert ok
+    exact = (U.astype(np.float64).T @ X.astype(np.float64)).T
+    f32p = ops.rotate(U, X, ctx=ctx)[:, :n]
+    bound = (np.abs(X.astype(np.float64)).T @ np.abs(U.astype(np.float64)))
+    err_g = np.abs(got[:, :n] - exact) / bound
+    err_f = np.abs(f32p - exact) / bound
+    assert err_g.max() <= 4 * 2.0 ** -24 * np.sqrt(n) and np.median(err_g) <= 2 * max(np.median(err_f), 1e-9)
+    assert (got[:, n:] == 0).all()
