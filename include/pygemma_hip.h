@@ -115,6 +115,13 @@ size_t pg_geno_work_bytes(int64_t n, int64_t p);
 int pg_geno_prep_dev(pg_ctx *ctx, int64_t n, const float *U, int64_t ldU, void *Uprep);
 int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const float *X_n_by_p, int64_t ldX, float *Xr,
                        int64_t ldx, void *work, int *is_geno);
+/* The same rotation straight from a PLINK .bed block (the format the reference's callers read with pysnptools.Bed,
+ * experiments/benchmarks/benchmarks.py:233-239): bed = device copy of p SNP records of ldb >= ceil(n/4) bytes (SNP-major,
+ * 2 bits per sample: 00 hom A1, 01 missing, 10 het, 11 hom A2).  Dosage = copies of A2 (count_a1 = 0, pysnptools
+ * count_A1=False) or of A1; missing calls take the mean of the called genotypes of their SNP (SimpleImputer 'mean',
+ * benchmarks.py:243-244).  16x fewer input bytes than float32 X.  work: pg_geno_work_bytes(n, p). */
+int pg_rotate_bed_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const unsigned char *bed, int64_t ldb, int count_a1,
+                      float *Xr, int64_t ldx, void *work);
 
 /* ---- N3: relatedness matrix from standardised genotypes, K = G G' / p_k
  * (experiments/animal_gwas/run_gwas.py:45-55, tests/test_pygemma.py:184-192).  Gt is the SNP-major (p_k x ldg)

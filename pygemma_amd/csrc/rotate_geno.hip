@@ -204,6 +204,39 @@ __global__ void params_geno_kernel(long long p, const int *kmin, const int *kmax
     dlt[g] = (other[g] == OTHER_EMPTY) ? 0.0f : __int_as_float(other[g]) - lo;   // exact or one rounding: folded in fp64 below
 }
 
+// PLINK .bed block (SNP-major, 4 samples per byte, sample k of a byte in bits 2k..2k+1: 00 hom A1, 01 missing, 10 het,
+// 11 hom A2) -> code plane, indicator plane of the missing calls and v0 = 0, dx = 1, delta = column mean of the called
+// genotypes (what SimpleImputer(strategy='mean') puts there, experiments/benchmarks/benchmarks.py:243-244).
+// Dosage = copies of A2 (pysnptools count_A1=False, benchmarks.py:233) or of A1 (count_a1).  One workgroup per SNP.
+__global__ __launch_bounds__(256) void decode_bed_kernel(long long n, long long p, const unsigned char *bed, long long ldb, int count_a1,
+                                                         unsigned short *Gt, unsigned short *Gi, long long ldk, float *v0, float *dx, float *dlt, int *flag)
+{
+    __shared__ unsigned cnt[3];
+    const long long g = blockIdx.x;
+    const unsigned char *row = bed + g * ldb;
+    if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned n1 = 0, n2 = 0, nm = 0;
+    for (long long i = threadIdx.x; i < ldk; i += blockDim.x) {
+        unsigned short code = 0, ind = 0;
+        if (i < n) {
+            const unsigned c = (row[i >> 2] >> (2 * (i & 3))) & 3u;
+            if (c == 1u) { ind = 0x3C00; nm++; }
+            else if (c == 2u) { code = 0x3C00; n1++; }
+            else if ((c == 3u) != (count_a1 != 0)) { code = 0x4000; n2++; }     // hom A2 counts 2 (A2 dosage) / hom A1 counts 2 (A1 dosage)
+        }
+        Gt[g * ldk + i] = code; Gi[g * ldk + i] = ind;
+    }
+    atomicAdd(&cnt[0], n1); atomicAdd(&cnt[1], n2); atomicAdd(&cnt[2], nm);   // integer sums: order-independent
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double called = (double)n - (double)cnt[2];
+        v0[g] = 0.0f; dx[g] = 1.0f;
+        dlt[g] = (cnt[2] > 0 && called > 0) ? (float)(((double)cnt[0] + 2.0 * (double)cnt[1]) / called) : 0.0f;
+        if (cnt[2] > 0) atomicOr(flag + 1, 1);
+    }
+}
+
 struct GenoParams {
     long long n, p, ldx, ldk, ldp;
     const unsigned short *Gt, *Up;
@@ -412,6 +445,29 @@ extern "C" int pg_geno_prep_dev(pg_ctx *ctx, int64_t n, const float *U, int64_t 
     return PG_OK;
 }
 
+static int launch_geno_gemm(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const unsigned short *Gt, const unsigned short *Gi,
+                            const float *v0, const float *dx, const float *dlt, float *Xr, int64_t ldx, bool second_pass)
+{
+    const long long kt = (n + GBK - 1) / GBK, ldk = kt * GBK, ldp = kt * 2 * GBK;
+    GenoParams gp{};
+    gp.n = n; gp.p = p; gp.ldx = ldx; gp.ldk = ldk; gp.ldp = ldp;
+    gp.Gt = Gt; gp.Up = (const unsigned short *)Uprep;
+    const double *sums = (const double *)((const char *)Uprep + (((size_t)n * ldp * 2 + 255) & ~(size_t)255));
+    gp.colsum = sums + (size_t)kt * n;
+    gp.scale = (const float *)(sums + (size_t)(kt + 1) * n);
+    gp.v0 = v0; gp.dx = dx; gp.Xr = Xr;
+    gp.tiles_m = (int)((p + GBM - 1) / GBM); gp.tiles_n = (int)((n + GBN - 1) / GBN); gp.KT = (int)kt;
+    const long long T = (long long)gp.tiles_m * gp.tiles_n;
+    PG_REQUIRE(T < (1LL << 31), "genotype rotation: too many tiles");
+    rotate_geno_kernel<<<dim3((unsigned)T), 512, 0, ctx->stream>>>(gp);
+    if (second_pass) {   // Xr += delta * U'ind
+        gp.Gt = Gi; gp.v0 = nullptr; gp.dx = dlt;
+        rotate_geno_kernel<<<dim3((unsigned)T), 512, 0, ctx->stream>>>(gp);
+    }
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
 // Rotate a block of genotype columns.  work must hold pg_geno_work_bytes(n, p).  *is_geno_host receives 1 when the block
 // qualified and Xr was written, 0 when it did not (Xr untouched: the caller falls back to pg_rotate_dev).  Synchronises.
 extern "C" size_t pg_geno_work_bytes(int64_t n, int64_t p)
@@ -443,22 +499,30 @@ extern "C" int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void 
     PG_HIP(hipStreamSynchronize(ctx->stream));
     *is_geno_host = hflag[0] ? 0 : 1;
     if (hflag[0]) return PG_OK;
-    GenoParams gp{};
-    gp.n = n; gp.p = p; gp.ldx = ldx; gp.ldk = ldk; gp.ldp = ldp;
-    gp.Gt = Gt; gp.Up = (const unsigned short *)Uprep;
-    const double *sums = (const double *)((const char *)Uprep + (((size_t)n * ldp * 2 + 255) & ~(size_t)255));
-    gp.colsum = sums + (size_t)kt * n;
-    gp.scale = (const float *)(sums + (size_t)(kt + 1) * n);
-    gp.v0 = v0; gp.dx = dx; gp.Xr = Xr;
-    gp.tiles_m = (int)((p + GBM - 1) / GBM); gp.tiles_n = (int)((n + GBN - 1) / GBN); gp.KT = (int)kt;
-    const long long T = (long long)gp.tiles_m * gp.tiles_n;
-    PG_REQUIRE(T < (1LL << 31), "pg_rotate_geno_dev: too many tiles");
-    rotate_geno_kernel<<<dim3((unsigned)T), 512, 0, ctx->stream>>>(gp);
-    if (hflag[1]) {   // second pass on the indicator plane: Xr += (other - v0) * U'ind
+    if (hflag[1])
         indicator_geno_kernel<<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk);
-        gp.Gt = Gi; gp.v0 = nullptr; gp.dx = dlt;
-        rotate_geno_kernel<<<dim3((unsigned)T), 512, 0, ctx->stream>>>(gp);
-    }
+    return launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, hflag[1] != 0);
+}
+
+// Rotate a block of PLINK .bed genotypes (device copy of the packed bytes: p rows of ldb >= ceil(n/4) bytes, SNP-major as in
+// the file).  Missing calls take the mean of the called genotypes of their SNP.  Same outputs as pg_rotate_geno_dev.
+extern "C" int pg_rotate_bed_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const unsigned char *bed, int64_t ldb, int count_a1,
+                                 float *Xr, int64_t ldx, void *work)
+{
+    PG_REQUIRE(ctx && Uprep && bed && Xr && work, "pg_rotate_bed_dev: NULL argument");
+    PG_REQUIRE(n > 0 && p > 0 && ldb >= (n + 3) / 4 && ldx >= n && ldx <= (n + 127) / 128 * 128, "pg_rotate_bed_dev: bad shape");
+    PG_HIP(hipSetDevice(ctx->device));
+    const long long kt = (n + GBK - 1) / GBK, ldk = kt * GBK;
+    const size_t plane = ((size_t)p * ldk * 2 + 255) & ~(size_t)255;
+    unsigned short *Gt = (unsigned short *)work, *Gi = (unsigned short *)((char *)work + plane);
+    char *tail = (char *)work + 2 * plane;
+    float *v0 = (float *)tail, *dx = v0 + p, *dlt = dx + p;
+    int *flag = (int *)(dlt + p) + 3 * p;
+    PG_HIP(hipMemsetAsync(flag, 0, 8, ctx->stream));
+    decode_bed_kernel<<<(unsigned)p, 256, 0, ctx->stream>>>(n, p, bed, ldb, count_a1, Gt, Gi, ldk, v0, dx, dlt, flag);
     PG_HIP(hipGetLastError());
-    return PG_OK;
+    int hflag[2] = {0, 0};
+    PG_HIP(hipMemcpyAsync(hflag, flag, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipStreamSynchronize(ctx->stream));
+    return launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, hflag[1] != 0);
 }

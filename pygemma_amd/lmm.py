@@ -21,6 +21,7 @@ import numpy as np
 import pandas as pd
 
 from . import _lib
+from .bed import PackedBed
 from .model import *          # noqa: F401,F403  (precompute_mat, calc_lambda_restricted, newton, the *_overload scalars)
 from . import model as _model
 
@@ -74,10 +75,12 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
             if eigen:   # genotype fast path of the rotation (<= 3 equally spaced values per column), fp32 MFMA otherwise
                 dprep = ctx.alloc(L.pg_geno_prep_bytes(n))
                 _lib.check(L.pg_geno_prep_dev(ctx.handle, n, dU.ptr, n, dprep.ptr), "pg_geno_prep_dev")
+            packed = isinstance(X, PackedBed)
             pb_max = max(256, int(_BATCH_BYTES // (4 * (n + ldx))) // 256 * 256)
             pb_max = min(pb_max, b - a)
             ldX = (pb_max + 3) // 4 * 4
-            dX = ctx.alloc(n * ldX * 4)
+            bpr = (n + 3) // 4
+            dX = ctx.alloc(pb_max * bpr if packed else n * ldX * 4)
             dXr = ctx.alloc(pb_max * ldx * 4)
             dout = ctx.alloc(pb_max * 16)
             dF = ctx.alloc(pb_max * 16)
@@ -87,8 +90,16 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
             for s in range(a, b, pb_max):
                 e = min(s + pb_max, b)
                 pb = e - s
-                _lib.check(L.pg_memcpy2d_h2d(ctx.handle, dX.ptr, ldX * 4, X.ctypes.data + 4 * s, p * 4, pb * 4, n), "pg_memcpy2d_h2d")
-                if eigen:
+                if packed:   # SNP records [s, e) of the .bed image: contiguous bytes, decoded + imputed + rotated on the device
+                    rec = np.ascontiguousarray(X.data[s:e])
+                    _lib.check(L.pg_memcpy_h2d(ctx.handle, dX.ptr, rec.ctypes.data, rec.nbytes), "pg_memcpy_h2d")
+                    _lib.check(L.pg_rotate_bed_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, bpr, int(X.count_A1), dXr.ptr, ldx, dwork.ptr),
+                               "pg_rotate_bed_dev")
+                else:
+                    _lib.check(L.pg_memcpy2d_h2d(ctx.handle, dX.ptr, ldX * 4, X.ctypes.data + 4 * s, p * 4, pb * 4, n), "pg_memcpy2d_h2d")
+                if packed:
+                    pass
+                elif eigen:
                     is_geno = C.c_int(0)
                     _lib.check(L.pg_rotate_geno_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx, dwork.ptr,
                                                     C.byref(is_geno)), "pg_rotate_geno_dev")
@@ -118,24 +129,32 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     Y (n,1) phenotype; X (n,p) genotypes; W (n,c) covariates; K (n,n) relatedness matrix — or, with
     eigen=False, the (n,) vector of its eigenvalues with X, Y, W already rotated (lmm.py:164-167).
     Returns a pandas.DataFrame with columns beta, se_beta, tau, lambda, F_wald, p_wald[, SNPs].
+    Beyond the reference: X may be a `pygemma_amd.bed.PackedBed` (PLINK .bed kept packed; missing calls mean-imputed on
+    the device, as the reference's callers do on the host before calling).
     """
     if de:
         # calculate_de is broken upstream (unpacks 4 of SampleIter's 5-tuple, lmm/lmm.py:499 vs :434)
         raise NotImplementedError("de=True is broken in the reference (lmm/lmm.py:499) and is not provided")
     L = _lib.load()
-    Y, X, W, K = np.asarray(Y), np.asarray(X), np.asarray(W), np.asarray(K)
+    packed = isinstance(X, PackedBed)                         # extension (SURVEY 8f N4): a PLINK .bed image instead of the float matrix
+    if packed and not eigen:
+        raise ValueError("a PackedBed holds raw genotypes: it cannot be used with eigen=False (pre-rotated inputs)")
+    Y, W, K = np.asarray(Y), np.asarray(W), np.asarray(K)
+    if not packed:
+        X = np.asarray(X)
     nproc = min(int(nproc), X.shape[1])                      # lmm.py:113
     if Y.dtype != np.float32:
         Y = Y.astype(np.float32).reshape(-1, 1)              # lmm.py:115-116
     if W.dtype != np.float32:
         W = W.astype(np.float32)                             # lmm.py:118-119
-    if X.dtype != np.float32:
+    if not packed and X.dtype != np.float32:
         X = X.astype(np.float32)                             # lmm.py:121-122
     if Z is not None:
         K = np.asarray(Z) @ K @ np.asarray(Z).T              # lmm.py:124-125
     if K.dtype != np.float32:
         K = K.astype(np.float32)                             # lmm.py:127-128
-    X = np.ascontiguousarray(X)
+    if not packed:
+        X = np.ascontiguousarray(X)
     n, p = X.shape
     c = W.shape[1]
     if Y.shape[0] != n or W.shape[0] != n:
@@ -171,7 +190,7 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     if not disable_checks:
         # lmm.py:253-256 (the reference tests the rotated arrays; a NaN anywhere in a raw column makes that
         # whole rotated column NaN, so testing the inputs raises in exactly the same cases)
-        if np.isnan(X).any() or np.isnan(Yr).any() or np.isnan(Wr).any():
+        if (not packed and np.isnan(X).any()) or np.isnan(Yr).any() or np.isnan(Wr).any():
             raise ValueError("NaNs present in data")
 
     _log(verbose, f"Running {p} SNPs with {n} individuals on {ndev} GPU(s)...")

@@ -76,3 +76,36 @@ def test_pygemma_full_pipeline_tier_c(grid):
         assert np.quantile(eb, 0.99) <= max(2.0 * np.quantile(er, 0.99), 5e-6), (col, eb.max(), er.max())
     relp = np.abs(df["p_wald"].to_numpy() - z[tag + "p_wald"]) / z[tag + "p_wald"]
     assert (relp <= 1e-3).mean() >= 0.99
+
+
+def test_pygemma_from_packed_bed_matches_float_input(tmp_path):
+    """N4: a PLINK .bed image (2 bits per call, missing calls present) handed to lmm.pygemma gives the results of the
+    float32 matrix the reference's callers would build from it (pysnptools count_A1=False + mean imputation)."""
+    from pygemma_amd import lmm, synth
+    from pygemma_amd.bed import PackedBed, write_bed
+    rng = np.random.default_rng(11)
+    n, p, c = 301, 700, 3                      # n not a multiple of 4: the last byte of every SNP record is partial
+    G = rng.binomial(2, rng.uniform(0.05, 0.5, p), size=(n, p)).astype(np.float64)
+    G[rng.random((n, p)) < 0.01] = np.nan
+    G[:, 5] = np.where(np.isnan(G[:, 5]), 0, G[:, 5])       # a SNP without missing calls
+    prefix = str(tmp_path / "toy")
+    write_bed(prefix, G)
+    bed = PackedBed.open(prefix + ".bed", count_A1=False)
+    assert bed.shape == (n, p) and len(bed.snps) == p
+    Xf = bed.to_float()
+    mu = np.nanmean(G, axis=0)
+    np.testing.assert_array_equal(Xf, np.where(np.isnan(G), mu[None, :], G).astype(np.float32))
+    GK = synth.genotypes(rng, n, 2 * n)
+    K = (GK @ GK.T / (2 * n)).astype(np.float32)
+    W = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, c - 1))], axis=1).astype(np.float32)
+    y = (0.3 * np.nan_to_num(G[:, 0]) + rng.standard_normal(n)).astype(np.float32).reshape(-1, 1)
+    a = lmm.pygemma(y, bed, W, K, snps=bed.snps)
+    b = lmm.pygemma(y, Xf, W, K, snps=bed.snps)
+    assert list(a.columns) == list(b.columns) and (a["SNPs"] == b["SNPs"]).all()
+    for col in ("beta", "se_beta", "tau", "lambda", "F_wald"):
+        np.testing.assert_allclose(a[col].to_numpy(), b[col].to_numpy(), rtol=2e-3, atol=1e-6, err_msg=col)
+    np.testing.assert_allclose(a["p_wald"].to_numpy(), b["p_wald"].to_numpy(), rtol=5e-3, atol=1e-12)
+    # A1 dosage = 2 - A2 dosage: beta flips sign, the test statistic does not change
+    a1 = lmm.pygemma(y, PackedBed.open(prefix, count_A1=True), W, K)
+    np.testing.assert_allclose(a1["beta"].to_numpy(), -a["beta"].to_numpy(), rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(a1["F_wald"].to_numpy(), a["F_wald"].to_numpy(), rtol=5e-3, atol=1e-6)

@@ -76,3 +76,26 @@ def test_drop_in_import_path():
     assert list(sig.parameters) == ["Y", "X", "W", "K", "Z", "snps", "verbose", "disable_checks", "de", "grid", "eigen", "nproc"]
     d = {k: v.default for k, v in sig.parameters.items() if v.default is not inspect._empty}
     assert d == {"Z": None, "snps": None, "verbose": 0, "disable_checks": True, "de": False, "grid": False, "eigen": True, "nproc": 1}
+
+
+def test_packed_bed_roundtrip(tmp_path):
+    """bed.py: write_bed -> PackedBed.open -> to_float reproduces the dosages (both allele conventions, NaN for missing)."""
+    import numpy as np
+    from pygemma_amd.bed import PackedBed, write_bed
+    rng = np.random.default_rng(5)
+    n, p = 37, 19
+    G = rng.integers(0, 3, size=(n, p)).astype(np.float64)
+    G[rng.random((n, p)) < 0.1] = np.nan
+    prefix = str(tmp_path / "t")
+    packed = write_bed(prefix, G)
+    assert packed.shape == (p, (n + 3) // 4)
+    b = PackedBed.open(prefix)
+    assert b.shape == (n, p) and b.snps[3] == "rs3"
+    np.testing.assert_array_equal(b.to_float(impute=False), G.astype(np.float32))
+    b1 = PackedBed.open(prefix + ".bed", count_A1=True)
+    np.testing.assert_array_equal(b1.to_float(impute=False), (2 - G).astype(np.float32))
+    with open(prefix + ".bed", "r+b") as f:
+        f.write(b"\x00")
+    import pytest
+    with pytest.raises(ValueError):
+        PackedBed.open(prefix)
