@@ -14,6 +14,8 @@ column blocks (lmm.py:427-434); results come back in block order = SNP order.
 There is no CPU fallback: without the HIP library or a GPU this raises.
 """
 import ctypes as C
+import json
+import os
 import threading
 import time
 
@@ -27,7 +29,8 @@ from . import model as _model
 
 __all__ = ["pygemma", "SampleIter"] + _model.__all__
 
-_BATCH_BYTES = 6 << 30   # device bytes for one SNP batch (raw block + rotated block)
+_BATCH_BYTES = 6 << 30   # device bytes for one SNP batch of one worker (raw block, rotated block, fp16 planes)
+_BATCH_SNPS = 32768      # SNPs per batch at most: the unit of copy/compute overlap and of checkpointing
 
 
 class SampleIter:
@@ -62,75 +65,117 @@ def _rotate_small(ctx, L, n, dU, A):
     return out
 
 
-def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs, verbose):
-    """One GPU: SNP columns [a,b) of X through (rotate | transpose) -> assoc, in batches."""
+_COLS = ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald")
+
+
+def _part_path(ckpt, s, e):
+    return os.path.join(ckpt, f"part_{s:012d}_{e:012d}.npz")
+
+
+def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs, verbose, ckpt=None):
+    """One GPU: SNP columns [a,b) of X through (rotate | transpose) -> assoc, in batches.  Two host threads per GPU, each with
+    its own stream and buffers, take batches from a shared list, so that the host->device copy of one batch overlaps the
+    kernels of the other.  With `ckpt` every finished batch is written to disk (and batches found there are not redone)."""
     try:
         L = _lib.load()
-        ctx = _lib.Context(device)
+        ctx0 = _lib.Context(device)
         try:
             ldx = (n + 63) // 64 * 64
-            dd, dW, dy = ctx.to_device(d), ctx.to_device(Wr), ctx.to_device(yr)
-            dU = ctx.to_device(U_host) if eigen else None
-            dprep = dwork = None
+            dd, dW, dy = ctx0.to_device(d), ctx0.to_device(Wr), ctx0.to_device(yr)
+            dU = ctx0.to_device(U_host) if eigen else None
+            dprep = None
             if eigen:   # genotype fast path of the rotation (<= 3 equally spaced values per column), fp32 MFMA otherwise
-                dprep = ctx.alloc(L.pg_geno_prep_bytes(n))
-                _lib.check(L.pg_geno_prep_dev(ctx.handle, n, dU.ptr, n, dprep.ptr), "pg_geno_prep_dev")
+                dprep = ctx0.alloc(L.pg_geno_prep_bytes(n))
+                _lib.check(L.pg_geno_prep_dev(ctx0.handle, n, dU.ptr, n, dprep.ptr), "pg_geno_prep_dev")
+            ctx0.sync()
             packed = isinstance(X, PackedBed)
-            pb_max = max(256, int(_BATCH_BYTES // (4 * (n + ldx))) // 256 * 256)
-            pb_max = min(pb_max, b - a)
+            pb_max = max(256, int(_BATCH_BYTES // (12 * ldx)) // 256 * 256)   # raw block + rotated block + two fp16 planes
+            pb_max = min(pb_max, _BATCH_SNPS, b - a)
             ldX = (pb_max + 3) // 4 * 4
             bpr = (n + 3) // 4
-            dX = ctx.alloc(pb_max * bpr if packed else n * ldX * 4)
-            dXr = ctx.alloc(pb_max * ldx * 4)
-            dout = ctx.alloc(pb_max * 16)
-            dF = ctx.alloc(pb_max * 16)
-            if eigen:
-                dwork = ctx.alloc(L.pg_geno_work_bytes(n, pb_max))
             p = X.shape[1]
+            todo = []
             for s in range(a, b, pb_max):
                 e = min(s + pb_max, b)
-                pb = e - s
-                if packed:   # SNP records [s, e) of the .bed image: contiguous bytes, decoded + imputed + rotated on the device
-                    rec = np.ascontiguousarray(X.data[s:e])
-                    _lib.check(L.pg_memcpy_h2d(ctx.handle, dX.ptr, rec.ctypes.data, rec.nbytes), "pg_memcpy_h2d")
-                    _lib.check(L.pg_rotate_bed_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, bpr, int(X.count_A1), dXr.ptr, ldx, dwork.ptr),
-                               "pg_rotate_bed_dev")
+                if ckpt and os.path.exists(_part_path(ckpt, s, e)):
+                    with np.load(_part_path(ckpt, s, e)) as z:
+                        for col in _COLS:
+                            out[col][s:e] = z[col]
+                    _log(verbose, f"GPU {device}: SNPs [{s},{e}) restored from {ckpt}")
                 else:
-                    _lib.check(L.pg_memcpy2d_h2d(ctx.handle, dX.ptr, ldX * 4, X.ctypes.data + 4 * s, p * 4, pb * 4, n), "pg_memcpy2d_h2d")
-                if packed:
-                    pass
-                elif eigen:
-                    is_geno = C.c_int(0)
-                    _lib.check(L.pg_rotate_geno_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx, dwork.ptr,
-                                                    C.byref(is_geno)), "pg_rotate_geno_dev")
-                    if not is_geno.value:
-                        _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dX.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
-                else:
-                    _lib.check(L.pg_transpose_dev(ctx.handle, n, pb, dX.ptr, ldX, dXr.ptr, ldx), "pg_transpose_dev")
-                _lib.check(L.pg_assoc_dev(ctx.handle, n, c, pb, dd.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, int(grid),
-                                          dout.ptr, dout.ptr + 4 * pb, dout.ptr + 8 * pb, dout.ptr + 12 * pb,
-                                          dF.ptr, dF.ptr + 8 * pb, None), "pg_assoc_dev")
-                ctx.sync()
-                res = dout.download((4, pb), np.float32)
-                FP = dF.download((2, pb), np.float64)
-                out["beta"][s:e], out["se_beta"][s:e], out["tau"][s:e] = res[0], res[1], res[2]
-                out["lambda"][s:e] = res[3].astype(np.float64)
-                out["F_wald"][s:e], out["p_wald"][s:e] = FP[0], FP[1]
-                _log(verbose, f"GPU {device}: SNPs [{s},{e}) done")
+                    todo.append((s, e))
+            lock = threading.Lock()
+
+            def worker():
+                try:
+                    ctx = _lib.Context(device)
+                    try:
+                        dX = ctx.alloc(pb_max * bpr if packed else n * ldX * 4)
+                        dXr = ctx.alloc(pb_max * ldx * 4)
+                        dout, dF = ctx.alloc(pb_max * 16), ctx.alloc(pb_max * 16)
+                        dwork = ctx.alloc(L.pg_geno_work_bytes(n, pb_max)) if eigen else None
+                        while True:
+                            with lock:
+                                if not todo or errs:
+                                    return
+                                s, e = todo.pop(0)
+                            pb = e - s
+                            if packed:   # SNP records [s, e) of the .bed image: contiguous bytes; decode + impute + rotate on the device
+                                rec = np.ascontiguousarray(X.data[s:e])
+                                _lib.check(L.pg_memcpy_h2d(ctx.handle, dX.ptr, rec.ctypes.data, rec.nbytes), "pg_memcpy_h2d")
+                                _lib.check(L.pg_rotate_bed_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, bpr, int(X.count_A1), dXr.ptr, ldx,
+                                                               dwork.ptr), "pg_rotate_bed_dev")
+                            else:
+                                _lib.check(L.pg_memcpy2d_h2d(ctx.handle, dX.ptr, ldX * 4, X.ctypes.data + 4 * s, p * 4, pb * 4, n),
+                                           "pg_memcpy2d_h2d")
+                                if eigen:
+                                    is_geno = C.c_int(0)
+                                    _lib.check(L.pg_rotate_geno_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx, dwork.ptr,
+                                                                    C.byref(is_geno)), "pg_rotate_geno_dev")
+                                    if not is_geno.value:
+                                        _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dX.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
+                                else:
+                                    _lib.check(L.pg_transpose_dev(ctx.handle, n, pb, dX.ptr, ldX, dXr.ptr, ldx), "pg_transpose_dev")
+                            _lib.check(L.pg_assoc_dev(ctx.handle, n, c, pb, dd.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, int(grid),
+                                                      dout.ptr, dout.ptr + 4 * pb, dout.ptr + 8 * pb, dout.ptr + 12 * pb,
+                                                      dF.ptr, dF.ptr + 8 * pb, None), "pg_assoc_dev")
+                            ctx.sync()
+                            res = dout.download((4, pb), np.float32)
+                            FP = dF.download((2, pb), np.float64)
+                            out["beta"][s:e], out["se_beta"][s:e], out["tau"][s:e] = res[0], res[1], res[2]
+                            out["lambda"][s:e] = res[3].astype(np.float64)
+                            out["F_wald"][s:e], out["p_wald"][s:e] = FP[0], FP[1]
+                            if ckpt:
+                                tmp = _part_path(ckpt, s, e) + ".tmp.npz"
+                                np.savez(tmp, **{col: out[col][s:e] for col in _COLS})
+                                os.replace(tmp, _part_path(ckpt, s, e))
+                            _log(verbose, f"GPU {device}: SNPs [{s},{e}) done")
+                    finally:
+                        ctx.close()
+                except Exception as ex:  # surfaced by the caller; never swallowed
+                    errs.append(ex)
+
+            workers = [threading.Thread(target=worker) for _ in range(min(2, len(todo)))]
+            for th in workers:
+                th.start()
+            for th in workers:
+                th.join()
         finally:
-            ctx.close()
+            ctx0.close()
     except Exception as ex:  # surfaced by the caller; never swallowed
         errs.append(ex)
 
 
-def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=False, grid=False, eigen=True, nproc=1):
+def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=False, grid=False, eigen=True, nproc=1,
+            checkpoint=None):
     """Per-SNP LMM association scan (GEMMA-style REML + Wald test) — signature of lmm/lmm.py:87.
 
     Y (n,1) phenotype; X (n,p) genotypes; W (n,c) covariates; K (n,n) relatedness matrix — or, with
     eigen=False, the (n,) vector of its eigenvalues with X, Y, W already rotated (lmm.py:164-167).
     Returns a pandas.DataFrame with columns beta, se_beta, tau, lambda, F_wald, p_wald[, SNPs].
     Beyond the reference: X may be a `pygemma_amd.bed.PackedBed` (PLINK .bed kept packed; missing calls mean-imputed on
-    the device, as the reference's callers do on the host before calling).
+    the device, as the reference's callers do on the host before calling); `checkpoint` names a directory that receives
+    every finished SNP batch, and a rerun with the same inputs picks up from what is there (the reference has no restart).
     """
     if de:
         # calculate_de is broken upstream (unpacks 4 of SampleIter's 5-tuple, lmm/lmm.py:499 vs :434)
@@ -197,11 +242,24 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     out = {"beta": np.empty(p, np.float32), "se_beta": np.empty(p, np.float32), "tau": np.empty(p, np.float32),
            "lambda": np.empty(p, np.float64), "F_wald": np.empty(p, np.float64), "p_wald": np.empty(p, np.float64)}
     errs, threads = [], []
+    if checkpoint:
+        os.makedirs(checkpoint, exist_ok=True)
+        key = {"n": int(n), "p": int(p), "c": int(c), "grid": bool(grid), "eigen": bool(eigen), "ndev": int(ndev),
+               "batch_snps": int(_BATCH_SNPS), "batch_bytes": int(_BATCH_BYTES),
+               "y_sum": float(np.asarray(Yr, np.float64).sum()), "d_sum": float(np.asarray(eigenVals, np.float64).sum())}
+        mf = os.path.join(checkpoint, "manifest.json")
+        if os.path.exists(mf):
+            with open(mf) as f:
+                if json.load(f) != key:
+                    raise ValueError(f"checkpoint directory {checkpoint} belongs to a different run (manifest mismatch)")
+        else:
+            with open(mf, "w") as f:
+                json.dump(key, f)
     t2 = time.time()
     yr1 = np.ascontiguousarray(Yr.reshape(-1), np.float32)
     for dev_id, (a, b) in enumerate(SampleIter(p, ndev)):
         th = threading.Thread(target=_run_block, args=(dev_id, a, b, n, c, eigenVals, Wr, yr1, X, U_host, grid, eigen,
-                                                       out, errs, verbose))
+                                                       out, errs, verbose, checkpoint))
         th.start()
         threads.append(th)
     for th in threads:

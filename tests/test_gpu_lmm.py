@@ -109,3 +109,31 @@ def test_pygemma_from_packed_bed_matches_float_input(tmp_path):
     a1 = lmm.pygemma(y, PackedBed.open(prefix, count_A1=True), W, K)
     np.testing.assert_allclose(a1["beta"].to_numpy(), -a["beta"].to_numpy(), rtol=2e-3, atol=1e-6)
     np.testing.assert_allclose(a1["F_wald"].to_numpy(), a["F_wald"].to_numpy(), rtol=5e-3, atol=1e-6)
+
+
+def test_checkpoint_restart(tmp_path, monkeypatch):
+    """N4: finished SNP batches are written under `checkpoint`; a rerun restores them, recomputes only what is missing and
+    returns the same frame; a directory from another run is refused."""
+    import os
+    from pygemma_amd import lmm, synth
+    monkeypatch.setattr(lmm, "_BATCH_SNPS", 512)
+    rp = synth.rotated_panel(200, 1500, 2, seed=4)
+    d, X, Y, W = rp["d"], rp["X"], rp["Y"], rp["W"]
+    ck = str(tmp_path / "ck")
+    ref = lmm.pygemma(Y, X, W, d, eigen=False)
+    a = lmm.pygemma(Y, X, W, d, eigen=False, checkpoint=ck)
+    parts = sorted(f for f in os.listdir(ck) if f.startswith("part_"))
+    assert len(parts) == 3 and os.path.exists(os.path.join(ck, "manifest.json"))
+    os.remove(os.path.join(ck, parts[1]))
+    # poison a surviving part: a restart must take it from disk, not recompute it
+    z = dict(np.load(os.path.join(ck, parts[0])))
+    z["beta"] = z["beta"] + 1.0
+    np.savez(os.path.join(ck, parts[0]), **z)
+    b = lmm.pygemma(Y, X, W, d, eigen=False, checkpoint=ck)
+    for col in ("se_beta", "tau", "lambda", "F_wald", "p_wald"):
+        assert (a[col].to_numpy() == ref[col].to_numpy()).all() and (b[col].to_numpy() == ref[col].to_numpy()).all()
+    assert (a["beta"].to_numpy() == ref["beta"].to_numpy()).all()
+    assert (b["beta"].to_numpy()[:512] == ref["beta"].to_numpy()[:512] + 1.0).all()
+    assert (b["beta"].to_numpy()[512:] == ref["beta"].to_numpy()[512:]).all()
+    with pytest.raises(ValueError):
+        lmm.pygemma(Y, X[:, :700], W, d, eigen=False, checkpoint=ck)
