@@ -248,6 +248,26 @@ def main():
     # algorithmic fp64 flops of the assoc stage per SNP: decade scan 11 lambdas x 2 powers x m entries x 2n,
     # + per SNP-specific evaluation m(m+1)/2 entries x (2 | 3) powers x 2n
     assoc_flops_snp = 11 * 2 * m * 2.0 * n + (stats[0] * 2 + stats[1] * 3) * (m * (m + 1) / 2) * 2.0 * n
+    rl_rotate = ({"kernel": "rotate_geno_kernel (+detect/encode): fp16 MFMA 16x16x32, U split in 2 fp16 planes, fp32 accumulate",
+                  "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12, "peak": BF16_MFMA_PEAK_TF / 2.0, "unit": "TFLOP/s",
+                  "frac": rot_flops / rot_avg / 1e12 / (BF16_MFMA_PEAK_TF / 2.0),
+                  "peak_note": "algorithmic 2n^2 flop/SNP against the dense fp16 MFMA peak (2500 TF) divided by the 2 fp16 passes a "
+                               "24-bit U needs; executed fp16 rate = 2x achieved",
+                  "traffic": pmc_traffic("rotate_geno_kernel") if (n, B) == (10000, 16384) else None,
+                  "algorithmic_bytes": 4.0 * n * B + 4.0 * n * n + 4.0 * ldx * B, "avg_launch_ms": rot_avg * 1e3}
+                 if geno_used[1] else
+                 {"kernel": "rotate_kernel<4> (fp32 MFMA 32x32x2)", "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12,
+                  "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": rot_flops / rot_avg / 1e12 / F32_MFMA_PEAK_TF,
+                  "traffic": pmc_traffic("rotate_kernel") if (n, B) == (10000, 16384) else None,
+                  "algorithmic_bytes": 4.0 * n * B + 4.0 * n * n + 4.0 * ldx * B, "avg_launch_ms": rot_avg * 1e3})
+    rl_assoc = {"kernel": "assoc_kernel<%d> (+setup, p-values): fp64 VALU FMAs of the Gram passes, wave per SNP" % c, "bound": "mfma",
+                "achieved": assoc_flops_snp * B / assoc_avg / 1e12, "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                "frac": assoc_flops_snp * B / assoc_avg / 1e12 / F64_VALU_PEAK_TF,
+                "peak_note": "fp64 vector peak = fp64 matrix peak on MI355X (78.6 TF); only the Gram FMAs are counted (conversions, "
+                             "h*w products, reciprocals, reductions and sweeps are not): the VALU issue port is ~82 % busy (profiles/)",
+                "traffic": pmc_traffic("assoc_kernel") if (n, B, c) == (10000, 16384, 5) else None,
+                "algorithmic_bytes": (4.0 * ldx + 36) * B, "avg_launch_ms": assoc_avg * 1e3,
+                "hbm_GBps_algorithmic": (4.0 * n + 36) * B / assoc_avg / 1e9}
     out = {
         "metric": "SNPs/sec (whole node) at n=10,000 c=5; K-eigendecomp wallclock",
         "value": value, "unit": "SNPs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -260,29 +280,15 @@ def main():
                    "parallelism": f"snp-shards x{world}"},
         "eigh_seconds": min(eigh_s),
         "eigh_note": "fp64 Householder tridiagonalisation + divide&conquer + back-transform on device, n=%d, one-time" % n,
-        "roofline": ({"kernel": "rotate_geno_kernel (+detect/encode): fp16 MFMA 16x16x32, U split in 2 fp16 planes, fp32 accumulate",
-                      "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12, "peak": BF16_MFMA_PEAK_TF / 2.0, "unit": "TFLOP/s",
-                      "frac": rot_flops / rot_avg / 1e12 / (BF16_MFMA_PEAK_TF / 2.0),
-                      "peak_note": "algorithmic 2n^2 flop/SNP against the dense fp16 MFMA peak (2500 TF) divided by the 2 fp16 passes a "
-                                   "24-bit U needs; executed fp16 rate = 2x achieved",
-                      "traffic": pmc_traffic("rotate_geno_kernel") if (n, B) == (10000, 16384) else None,
-                      "algorithmic_bytes": 4.0 * n * B + 4.0 * n * n + 4.0 * ldx * B, "avg_launch_ms": rot_avg * 1e3}
-                     if geno_used[1] else
-                     {"kernel": "rotate_kernel<4> (fp32 MFMA 32x32x2)", "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12,
-                      "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": rot_flops / rot_avg / 1e12 / F32_MFMA_PEAK_TF,
-                      "traffic": pmc_traffic("rotate_kernel") if (n, B) == (10000, 16384) else None,
-                      "algorithmic_bytes": 4.0 * n * B + 4.0 * n * n + 4.0 * ldx * B, "avg_launch_ms": rot_avg * 1e3}),
+        # the dominant kernel of the step = the longer of the two launches
+        "roofline": rl_assoc if assoc_avg >= rot_avg else rl_rotate,
+        "roofline_rotate": rl_rotate,
+        "roofline_assoc": rl_assoc,
         "roofline_fp32_rotate": {"kernel": "rotate_kernel<4> (fp32 MFMA 32x32x2; the path for non-genotype X)", "bound": "mfma",
                                  "achieved": rot_flops / t_f32 / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                                  "frac": rot_flops / t_f32 / 1e12 / F32_MFMA_PEAK_TF, "avg_launch_ms": t_f32 * 1e3,
                                  "traffic": pmc_traffic("rotate_kernel") if (n, B) == (10000, 16384) else None},
         "rotation_path": "genotype f16x2" if geno_used[1] else "fp32 MFMA",
-        "roofline_assoc": {"kernel": "assoc_kernel<%d> (+setup, p-values; fp64 VALU)" % c, "bound": "mfma",
-                           "achieved": assoc_flops_snp * B / assoc_avg / 1e12, "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": assoc_flops_snp * B / assoc_avg / 1e12 / F64_VALU_PEAK_TF,
-                           "traffic": pmc_traffic("assoc_kernel") if (n, B, c) == (10000, 16384, 5) else None,
-                           "avg_launch_ms": assoc_avg * 1e3,
-                           "hbm_GBps_algorithmic": (4.0 * n + 36) * B / assoc_avg / 1e9},
         "stage_snps_per_s_per_gpu": {"rotate": B / rot_avg, "assoc": B / assoc_avg},
         "evals_per_snp": {"fast": float(stats[0]), "newton": float(stats[1])},
         "lambda_median": float(np.median(lam)),
