@@ -44,13 +44,37 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
     return t;
 }
 
-// Per column i of the panel (ci = i - i0 columns already in it) four launches:
+// sum of cnt partials, the same additions on every wavefront of every workgroup (lane-strided, then xor butterfly)
+__device__ __forceinline__ double det_sum(const double *p, int cnt)
+{
+    double s = 0.0;
+    for (int b = threadIdx.x & 63; b < cnt; b += 64) s += p[b];
+    for (int st = 1; st < 64; st <<= 1) s += __shfl_xor(s, st, 64);
+    return s;
+}
+// Householder scalars of column i from alpha = a[i+1] and |a[i+2:]|^2 (dlarfg)
+__device__ __forceinline__ void larfg_scalars(double alpha, double xnorm2, double &beta, double &tau, double &scal)
+{
+    if (xnorm2 == 0.0) { beta = alpha; tau = 0.0; scal = 0.0; }
+    else {
+        beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+        tau = (beta - alpha) / beta;
+        scal = 1.0 / (alpha - beta);
+    }
+}
+// element r of the reflector v_i (v[i+1] = 1, zeros above), from the un-scaled column a
+__device__ __forceinline__ double vval(const double *acol, double scal, int i, int r)
+{
+    return (r == i + 1) ? 1.0 : ((r > i + 1) ? acol[r] * scal : 0.0);
+}
+
+// Per column i of the panel (ci = i - i0 columns already in it) three launches:
 //   col_kernel      : finish W[ci-1] (needs the global w.v of the previous column), form column i of A with the
 //                     pending panel updates  a = A[:,i] - V W[i,:]' - W V[i,:]'  and partial sums of |a[i+2:]|^2
-//   larfg_kernel    : Householder reflector of a[i+1:] (multi-workgroup; every workgroup re-derives beta/tau)
+//   (no launch of its own: every consumer derives beta, tau and the scale of v from the norm partials, v_r = a_r * scal)
 //   symv_dots_kernel: y = A[i+1:, i+1:] v (HBM-bound, 16-byte loads, one wavefront per row) and, in extra
 //                     workgroups, the 2*ci panel dot products W[c,:].v, V[c,:].v
-//   w_update_kernel : w = tau (y - V t1 - W t2) and partial sums of w.v
+//   w_update_kernel : w = tau (y - V t1 - W t2), partial sums of w.v; stores v into the panel, Vall and vcur
 // P = [V ; W ; V] stacked (3*NB x n), panel column c of V at P[c*n + r], of W at P[(NB+c)*n + r]
 __global__ __launch_bounds__(256) void col_kernel(int n, int i, int ci, int nblk_prev, const double *A, double *P, const double *vprev,
                                                   const double *wtmp, const double *tauvec, const double *wvpart, double *acol, double *normpart)
@@ -63,8 +87,7 @@ __global__ __launch_bounds__(256) void col_kernel(int n, int i, int ci, int nblk
     double *V = P, *W = P + (size_t)NB * n;
     double alpha = 0.0, wi = 0.0;
     if (ci > 0) {
-        double dot = 0.0;
-        for (int b = 0; b < nblk_prev; b++) dot += wvpart[b];
+        const double dot = det_sum(wvpart, nblk_prev);
         alpha = -0.5 * tauvec[i - 1] * dot;
         wi = wtmp[i] + alpha * vprev[i];              // W[ci-1][i]
     }
@@ -91,58 +114,28 @@ __global__ __launch_bounds__(256) void col_kernel(int n, int i, int ci, int nblk
     if (threadIdx.x == 0) normpart[blockIdx.x] = sq;
 }
 
-// v (v[i+1] = 1, zeros above) -> panel column ci of V (both copies), column i of Vall, vcur; d[i], e[i], tau[i]
-__global__ __launch_bounds__(256) void larfg_kernel(int n, int i, int ci, int nblk_col, const double *acol, const double *normpart,
-                                                    double *P, double *Vall, double *vcur, double *dvec, double *evec, double *tauvec)
-{
-    double xnorm2 = 0.0;
-    for (int b = 0; b < nblk_col; b++) xnorm2 += normpart[b];
-    const double alpha = acol[i + 1];
-    double beta, tau, scal;
-    if (xnorm2 == 0.0) { beta = alpha; tau = 0.0; scal = 0.0; }
-    else {
-        beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
-        tau = (beta - alpha) / beta;
-        scal = 1.0 / (alpha - beta);
-    }
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) {
-        double v = 0.0;
-        if (r == i + 1) v = 1.0;
-        else if (r > i + 1) v = acol[r] * scal;
-        P[(size_t)ci * n + r] = v; P[(size_t)(2 * NB + ci) * n + r] = v; vcur[r] = v;
-        Vall[(size_t)r * n + i] = v;
-    }
-    if (r == 0) { dvec[i] = acol[i]; evec[i] = beta; tauvec[i] = tau; }
-}
-
-__global__ __launch_bounds__(256) void symv_dots_kernel(int n, int i, int ci, int nsymv, const double *A, const double *P, const double *v,
+__global__ __launch_bounds__(256) void symv_dots_kernel(int n, int i, int ci, int nsymv, const double *A, const double *P, const double *acol,
+                                                        const double *normpart, int nblk_col, double *hh, double *dvec, double *evec, double *tauvec,
                                                         double *y, double *t)
 {
     __shared__ double sh[4];
+    double beta, tau, scal;
+    larfg_scalars(acol[i + 1], det_sum(normpart, nblk_col), beta, tau, scal);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { hh[0] = beta; hh[1] = tau; hh[2] = scal; dvec[i] = acol[i]; evec[i] = beta; tauvec[i] = tau; }
     if ((int)blockIdx.x < nsymv) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         const int r = i + 1 + blockIdx.x * 4 + wave;
         if (r >= n) return;
         const double *row = A + (size_t)r * n;
         double acc = 0.0;
-        if ((n & 1) == 0) {
-            // v[c] = 0 for c <= i, so starting one element early (even index) is harmless and keeps 16-byte alignment
-            for (int c = ((i + 1) & ~1) + 2 * lane; c < n; c += 128) {
-                const double2 a = *reinterpret_cast<const double2 *>(row + c), x = *reinterpret_cast<const double2 *>(v + c);
-                acc = fma(a.x, x.x, acc);
-                acc = fma(a.y, x.y, acc);
-            }
-        } else {
-            for (int c = i + 1 + lane; c < n; c += 64) acc = fma(row[c], v[c], acc);
-        }
+        for (int c = i + 1 + lane; c < n; c += 64) acc = fma(row[c], vval(acol, scal, i, c), acc);
         for (int s = 1; s < 64; s <<= 1) acc += __shfl_xor(acc, s, 64);
         if (lane == 0) y[r] = acc;
     } else {
         const int b = blockIdx.x - nsymv;   // t[b] = W[b,:].v (b < ci) ; t[ci + b] = V[b,:].v
         const double *src = (b < ci) ? P + (size_t)(NB + b) * n : P + (size_t)(b - ci) * n;
         double acc = 0.0;
-        for (int r = i + 1 + threadIdx.x; r < n; r += blockDim.x) acc = fma(src[r], v[r], acc);
+        for (int r = i + 1 + threadIdx.x; r < n; r += blockDim.x) acc = fma(src[r], vval(acol, scal, i, r), acc);
         acc = block_sum(acc, sh);
         if (threadIdx.x == 0) t[b] = acc;
     }
@@ -203,22 +196,28 @@ __device__ __forceinline__ double symv_half(int n, int rbase, int c0, bool cok, 
     return tot;
 }
 
-__global__ __launch_bounds__(256) void symv_sym_kernel(int n, int i, int ci, int nbr, const double *A, const double *P, const double *v,
+__global__ __launch_bounds__(256) void symv_sym_kernel(int n, int i, int ci, int nbr, const double *A, const double *P, const double *acol,
+                                                       const double *normpart, int nblk_col, double *hh, double *dvec, double *evec, double *tauvec,
                                                        double *rowpart, double *colpart, double *t)
 {
     __shared__ double sh[4];
     __shared__ double vrows[64];
     const int s = i + 1, cb = s & ~1, delta = s - cb;
+    double beta, tau, scal;
+    larfg_scalars(acol[i + 1], det_sum(normpart, nblk_col), beta, tau, scal);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        hh[0] = beta; hh[1] = tau; hh[2] = scal; dvec[i] = acol[i]; evec[i] = beta; tauvec[i] = tau;
+    }
     if ((int)blockIdx.x < nbr) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         const int I = blockIdx.x, J = blockIdx.y * 4 + wave;
         const int r0 = s + 64 * I;
-        if (threadIdx.x < 64) vrows[threadIdx.x] = (r0 + threadIdx.x < n) ? v[r0 + threadIdx.x] : 0.0;
+        if (threadIdx.x < 64) vrows[threadIdx.x] = (r0 + threadIdx.x < n) ? vval(acol, scal, i, r0 + threadIdx.x) : 0.0;
         __syncthreads();
         if (J > (64 * I + 63 + delta) / 128) return;
         const int c0 = cb + 128 * J + 2 * lane;
         const bool cok = c0 < n;                       // n even and c0 even: c0 + 1 < n as well
-        const double vc0 = cok ? v[c0] : 0.0, vc1 = cok ? v[c0 + 1] : 0.0;
+        const double vc0 = cok ? vval(acol, scal, i, c0) : 0.0, vc1 = cok ? vval(acol, scal, i, c0 + 1) : 0.0;
         const double *Ac = A + (cok ? c0 : 0);
         const bool interior = (r0 + 64 <= n) && (cb + 128 * J + 127 < r0);   // every column left of every row, all in range
         double col0 = 0.0, col1 = 0.0;
@@ -234,22 +233,23 @@ __global__ __launch_bounds__(256) void symv_sym_kernel(int n, int i, int ci, int
         const int b = blockIdx.x - nbr;   // t[b] = W[b,:].v (b < ci) ; t[ci + b] = V[b,:].v
         const double *src = (b < ci) ? P + (size_t)(NB + b) * n : P + (size_t)(b - ci) * n;
         double acc = 0.0;
-        for (int r = i + 1 + threadIdx.x; r < n; r += blockDim.x) acc = fma(src[r], v[r], acc);
+        for (int r = i + 1 + threadIdx.x; r < n; r += blockDim.x) acc = fma(src[r], vval(acol, scal, i, r), acc);
         acc = block_sum(acc, sh);
         if (threadIdx.x == 0) t[b] = acc;
     }
 }
 
 template <bool SYM>
-__global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, int nbr, const double *P, const double *v, const double *y,
-                                                       const double *rowpart, const double *colpart, const double *t, const double *tauvec,
-                                                       double *wtmp, double *partial)
+__global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, int nbr, double *P, const double *acol, const double *hh, const double *y,
+                                                       const double *rowpart, const double *colpart, const double *t,
+                                                       double *Vall, double *vcur, double *wtmp, double *partial)
 {
     __shared__ double part[4][64];
     __shared__ double sh[4];
     const int rr = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int r = i + 1 + blockIdx.x * 64 + rr;
     const double *V = P, *W = P + (size_t)NB * n;
+    const double tau = hh[1], scal = hh[2];
     double acc = 0.0;
     if (r < n) {
 #pragma unroll 4
@@ -272,9 +272,12 @@ __global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, int
     double wv = 0.0;
     if (cg == 0 && r < n) {
         acc = (SYM ? 0.0 : y[r]) + (((part[0][rr] + part[1][rr]) + part[2][rr]) + part[3][rr]);
-        acc *= tauvec[i];
+        acc *= tau;
         wtmp[r] = acc;
-        wv = acc * v[r];
+        const double v = vval(acol, scal, i, r);       // the reflector, stored here for everything downstream
+        P[(size_t)ci * n + r] = v; P[(size_t)(2 * NB + ci) * n + r] = v; vcur[r] = v;
+        Vall[(size_t)r * n + i] = v;
+        wv = acc * v;
     }
     wv = block_sum(wv, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = wv;
@@ -285,16 +288,16 @@ __global__ __launch_bounds__(256) void w_final_kernel(int n, int i, int ci, int 
                                                       const double *tauvec, const double *partial)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    double dot = 0.0;
-    for (int b = 0; b < nblk; b++) dot += partial[b];
+    const double dot = det_sum(partial, nblk);        // before the bounds check: every lane takes part in the shuffles
     const double alpha = -0.5 * tauvec[i] * dot;
+    if (r >= n) return;
     P[(size_t)(NB + ci) * n + r] = (r > i) ? wtmp[r] + alpha * v[r] : 0.0;
 }
 
 struct SytrdWork {
     double *A = nullptr, *P = nullptr, *Vall = nullptr, *acol = nullptr, *vcur = nullptr, *y = nullptr, *t = nullptr,
            *wtmp = nullptr, *partial = nullptr, *d = nullptr, *e = nullptr, *tau = nullptr, *rowpart = nullptr, *colpart = nullptr;
+    // t: [0, 2*NB) panel dot products, [2*NB, 2*NB+3) beta/tau/scale of the current column
     // partial: [0, n/64+2) w.v partial sums, [n/64+2, 2(n/64+2)) column-norm partial sums
 };
 
@@ -312,17 +315,18 @@ static int sytrd_device(pg_ctx *ctx, int n, SytrdWork &w)
             const int i = i0 + ci;
             const int nblk_col = (n - i + 63) / 64;
             col_kernel<<<nblk_col, 256, 0, s>>>(n, i, ci, nblk_prev, w.A, w.P, w.vcur, w.wtmp, w.tau, w.partial, w.acol, normpart);
-            larfg_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, i, ci, nblk_col, w.acol, normpart, w.P, w.Vall, w.vcur, w.d, w.e, w.tau);
+            double *hh = w.t + 2 * NB;
             const int nt = n - i - 1;
             const int nblk = (nt + 63) / 64;
             if ((n & 1) == 0 && w.rowpart) {
                 const int nbr = nblk, ywaves = (64 * (nbr - 1) + 64) / 128 + 1;
-                symv_sym_kernel<<<dim3(nbr + 2 * ci, (ywaves + 3) / 4), 256, 0, s>>>(n, i, ci, nbr, w.A, w.P, w.vcur, w.rowpart, w.colpart, w.t);
-                w_update_kernel<true><<<nblk, 256, 0, s>>>(n, i, ci, nbr, w.P, w.vcur, w.y, w.rowpart, w.colpart, w.t, w.tau, w.wtmp, w.partial);
+                symv_sym_kernel<<<dim3(nbr + 2 * ci, (ywaves + 3) / 4), 256, 0, s>>>(n, i, ci, nbr, w.A, w.P, w.acol, normpart, nblk_col, hh, w.d, w.e, w.tau,
+                                                                                  w.rowpart, w.colpart, w.t);
+                w_update_kernel<true><<<nblk, 256, 0, s>>>(n, i, ci, nbr, w.P, w.acol, hh, w.y, w.rowpart, w.colpart, w.t, w.Vall, w.vcur, w.wtmp, w.partial);
             } else {
                 const int nsymv = (nt + 3) / 4;
-                symv_dots_kernel<<<nsymv + 2 * ci, 256, 0, s>>>(n, i, ci, nsymv, w.A, w.P, w.vcur, w.y, w.t);
-                w_update_kernel<false><<<nblk, 256, 0, s>>>(n, i, ci, nblk, w.P, w.vcur, w.y, w.rowpart, w.colpart, w.t, w.tau, w.wtmp, w.partial);
+                symv_dots_kernel<<<nsymv + 2 * ci, 256, 0, s>>>(n, i, ci, nsymv, w.A, w.P, w.acol, normpart, nblk_col, hh, w.d, w.e, w.tau, w.y, w.t);
+                w_update_kernel<false><<<nblk, 256, 0, s>>>(n, i, ci, nblk, w.P, w.acol, hh, w.y, w.rowpart, w.colpart, w.t, w.Vall, w.vcur, w.wtmp, w.partial);
             }
             nblk_prev = nblk;
             if (ci == nbc - 1) w_final_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, i, ci, nblk, w.P, w.vcur, w.wtmp, w.tau, w.partial);
@@ -797,12 +801,13 @@ extern "C" int pgx_sytrd_dev(pg_ctx *ctx, int64_t n64, const float *K, double *d
     SytrdWork w;
     int rc = PG_OK;
     double **bufs[] = {&w.A, &w.P, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial, &w.rowpart, &w.colpart};
-    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, 2 * ((size_t)n / 64 + 2),
+    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB + 8, (size_t)n, 2 * ((size_t)n / 64 + 2),
                       ((size_t)n / 128 + 2) * n, ((size_t)n / 64 + 2) * n};
     for (int k = 0; k < 10 && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
     w.Vall = Vall; w.d = d; w.e = e; w.tau = tau;
     if (!rc) {
         sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, ctx->stream>>>(n, K, w.A);
+        (void)hipMemsetAsync(w.Vall, 0, (size_t)n * n * 8, ctx->stream);   // rows <= i of reflector i are never written
         rc = sytrd_device(ctx, n, w);
     }
     (void)hipStreamSynchronize(ctx->stream);
@@ -895,7 +900,7 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
     int rc = PG_OK;
     double **bufs[] = {&w.A, &w.P, &w.Vall, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial, &w.d, &w.e, &w.tau, &G, &T, &W, &W2, &dev_ev,
                        &w.rowpart, &w.colpart};
-    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB, (size_t)n, 2 * ((size_t)n / 64 + 2),
+    size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB + 8, (size_t)n, 2 * ((size_t)n / 64 + 2),
                       (size_t)n, (size_t)n, (size_t)n, (size_t)NB * NB, (size_t)NB * NB, (size_t)NB * n, (size_t)NB * n, (size_t)n,
                       ((size_t)n / 128 + 2) * n, ((size_t)n / 64 + 2) * n};
     const int nbuf = (int)(sizeof(sizes) / sizeof(sizes[0]));
