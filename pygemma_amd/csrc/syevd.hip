@@ -259,10 +259,12 @@ __global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, int
             const int s = i + 1, cb = s & ~1, delta = s - cb;
             const int Ir = (r - s) >> 6, nJ = (64 * Ir + 63 + delta) / 128 + 1;
             double ya = 0.0;
+#pragma unroll 8
             for (int J = cg; J < nJ; J += 4) ya += rowpart[(size_t)J * n + r];
             const int Jc = (r - cb) >> 7;
             int Imin = (128 * Jc - delta) / 64;
             if (Jc == 0) Imin = 0;
+#pragma unroll 8
             for (int I = Imin + cg; I < nbr; I += 4) ya += colpart[(size_t)I * n + r];
             acc += ya;
         }
@@ -837,17 +839,23 @@ extern "C" int pgx_stedc_dev(pg_ctx *ctx, int64_t n64, const double *d_host, con
 
 // compact-WY factor of a block of reflectors (forward, columnwise):  H_0 ... H_{m-1} = I - V T V'
 // G = V'V (m x m, ld NB).  T upper triangular (ld NB).  One workgroup.
+// Back-transformation block: BB reflectors = BB/NB sub-blocks of NB.  T (BB x BB, upper triangular, compact WY:
+// H_0 .. H_{m-1} = I - V T V') is built from the Gram matrix G = V'V: the NB x NB diagonal blocks by the dlarft
+// recurrence (one workgroup per sub-block), the off-diagonal block columns by T(0:r, r:r+w) = -T(0:r,0:r) G(0:r, r:r+w) T(r:r+w, r:r+w).
+constexpr int BB = 256;
 __global__ __launch_bounds__(64) void larft_kernel(int m, const double *G, const double *tau, double *T)
 {
     __shared__ double Ts[NB][NB + 1];
+    const int off = blockIdx.x * NB, mb = (m - off < NB) ? m - off : NB;
+    G += (size_t)off * BB + off; T += (size_t)off * BB + off; tau += off;
     const int i = threadIdx.x;
     for (int j = 0; j < NB; j++) if (i < NB) Ts[i][j] = 0.0;
     __syncthreads();
-    for (int j = 0; j < m; j++) {
+    for (int j = 0; j < mb; j++) {
         const double tj = tau[j];
         double v = 0.0;
         if (i < j) {
-            for (int l = i; l < j; l++) v += Ts[i][l] * G[(size_t)l * NB + j];
+            for (int l = i; l < j; l++) v += Ts[i][l] * G[(size_t)l * BB + j];
             v *= -tj;
         }
         __syncthreads();
@@ -855,7 +863,7 @@ __global__ __launch_bounds__(64) void larft_kernel(int m, const double *G, const
         if (i == j) Ts[j][j] = tj;
         __syncthreads();
     }
-    for (int j = 0; j < NB; j++) if (i < NB) T[(size_t)i * NB + j] = Ts[i][j];
+    for (int j = 0; j < NB; j++) if (i < NB) T[(size_t)i * BB + j] = Ts[i][j];
 }
 
 __global__ void finalize_kernel(long long n, const double *X, const double *ev, float *U32, float *ev32)
@@ -868,19 +876,28 @@ __global__ void finalize_kernel(long long n, const double *X, const double *ev, 
 // Z <- Q Z with Q = H_0 H_1 ... H_{n-2} (reflectors in Vall columns, scalars tau on the device)
 static int backtransform_device(pg_ctx *ctx, int n, const double *Vall, const double *tau, double *Z, double *G, double *T, double *W, double *W2)
 {
+    // G, T: BB x BB;  W, W2: BB x n.  Blocks of BB = 256 reflectors: every block is one read-modify-write pass over the
+    // rows i0.. of Z, so wide blocks cut that HBM traffic (the NB = 64 panels of the tridiagonalisation made 157 passes).
     hipStream_t s = ctx->stream;
     const int nref = n - 1;
-    const int nblk = (nref + NB - 1) / NB;
+    const int nblk = (nref + BB - 1) / BB;
     for (int b = nblk - 1; b >= 0; b--) {
-        const int i0 = b * NB, m = std::min(NB, nref - i0);
+        const int i0 = b * BB, m = std::min(BB, nref - i0), nsub = (m + NB - 1) / NB;
         const double *V = Vall + (size_t)i0 * n + i0;   // rows i0.., columns i0..i0+m-1 (row i0 itself is zero)
         const long long rows = n - i0;
-        int rc = dgemm(ctx, true, m, m, rows, 1.0, V, n, V, n, 0.0, G, NB);
+        int rc = dgemm(ctx, true, m, m, rows, 1.0, V, n, V, n, 0.0, G, BB);
         if (rc) return rc;
-        larft_kernel<<<1, 64, 0, s>>>(m, G, tau + i0, T);
+        PG_HIP(hipMemsetAsync(T, 0, (size_t)BB * BB * sizeof(double), s));
+        larft_kernel<<<nsub, 64, 0, s>>>(m, G, tau + i0, T);
         PG_HIP(hipGetLastError());
+        for (int k = 1; k < nsub; k++) {     // block column k of T; W is free here and serves as scratch
+            const int r = k * NB, wdt = std::min(NB, m - r);
+            rc = dgemm(ctx, false, r, wdt, r, 1.0, T, BB, G + r, BB, 0.0, W, NB);                         // X = T(0:r,0:r) G(0:r, r:r+w)
+            if (!rc) rc = dgemm(ctx, false, r, wdt, wdt, -1.0, W, NB, T + (size_t)r * BB + r, BB, 0.0, T + r, BB);   // T(0:r, r:r+w) = -X T_kk
+            if (rc) return rc;
+        }
         rc = dgemm(ctx, true, m, n, rows, 1.0, V, n, Z + (size_t)i0 * n, n, 0.0, W, n);          // W  = V' Z
-        if (!rc) rc = dgemm(ctx, false, m, n, m, 1.0, T, NB, W, n, 0.0, W2, n);                  // W2 = T W
+        if (!rc) rc = dgemm(ctx, false, m, n, m, 1.0, T, BB, W, n, 0.0, W2, n);                  // W2 = T W
         if (!rc) rc = dgemm(ctx, false, rows, n, m, -1.0, V, n, W2, n, 1.0, Z + (size_t)i0 * n, n);  // Z -= V W2
         if (rc) return rc;
     }
@@ -901,7 +918,7 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
     double **bufs[] = {&w.A, &w.P, &w.Vall, &w.acol, &w.vcur, &w.y, &w.t, &w.wtmp, &w.partial, &w.d, &w.e, &w.tau, &G, &T, &W, &W2, &dev_ev,
                        &w.rowpart, &w.colpart};
     size_t sizes[] = {(size_t)n * n, (size_t)3 * NB * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)2 * NB + 8, (size_t)n, 2 * ((size_t)n / 64 + 2),
-                      (size_t)n, (size_t)n, (size_t)n, (size_t)NB * NB, (size_t)NB * NB, (size_t)NB * n, (size_t)NB * n, (size_t)n,
+                      (size_t)n, (size_t)n, (size_t)n, (size_t)BB * BB, (size_t)BB * BB, (size_t)BB * n, (size_t)BB * n, (size_t)n,
                       ((size_t)n / 128 + 2) * n, ((size_t)n / 64 + 2) * n};
     const int nbuf = (int)(sizeof(sizes) / sizeof(sizes[0]));
     auto cleanup = [&]() {
