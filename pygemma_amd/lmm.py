@@ -82,7 +82,8 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
         try:
             ldx = (n + 63) // 64 * 64
             dd, dW, dy = ctx0.to_device(d), ctx0.to_device(Wr), ctx0.to_device(yr)
-            dU = ctx0.to_device(U_host) if eigen else None
+            # U: already resident (GPU 0 keeps the eigensolver's output) or uploaded from the host copy
+            dU = (U_host if isinstance(U_host, _lib.DeviceBuffer) else ctx0.to_device(U_host)) if eigen else None
             dprep = None
             if eigen:   # genotype fast path of the rotation (<= 3 equally spaced values per column), fp32 MFMA otherwise
                 dprep = ctx0.alloc(L.pg_geno_prep_bytes(n))
@@ -210,22 +211,29 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     ndev = max(1, min(nproc, ngpu))
 
     t0 = time.time()
-    U_host = None
+    U_host = None      # host copy of U: only needed to seed GPUs other than 0
+    ectx = dU0 = None  # the eigensolver's context on GPU 0 and U resident there (reused by GPU 0's SNP loop)
     if eigen:
         if K.shape != (n, n):
             raise ValueError(f"K must be ({n},{n}) when eigen=True, got {K.shape}")
-        with _lib.Context(0) as ctx:
-            dK = ctx.to_device(K)
-            dev, dU = ctx.alloc(n * 4), ctx.alloc(n * n * 4)
-            _lib.check(L.pg_syevd_dev(ctx.handle, n, dK.ptr, dev.ptr, dU.ptr, None, None), "pg_syevd_dev")
+        ectx = _lib.Context(0)
+        try:
+            dK = ectx.to_device(K)
+            dev, dU0 = ectx.alloc(n * 4), ectx.alloc(n * n * 4)
+            _lib.check(L.pg_syevd_dev(ectx.handle, n, dK.ptr, dev.ptr, dU0.ptr, None, None), "pg_syevd_dev")
+            dK.free()
             eigenVals = dev.download((n,), np.float32)       # ascending, clamped >= 0, float32 (lmm.py:152-160)
             assert (eigenVals >= 0).all()                    # lmm.py:162
             _log(verbose, f"Eigendecomposition computed - {time.time() - t0:.3f} s")
             t1 = time.time()
-            YW = _rotate_small(ctx, L, n, dU, np.concatenate([Y.reshape(n, -1)[:, :1], W], axis=1))
+            YW = _rotate_small(ectx, L, n, dU0, np.concatenate([Y.reshape(n, -1)[:, :1], W], axis=1))
             Yr, Wr = YW[:, :1], np.ascontiguousarray(YW[:, 1:])
-            U_host = dU.download((n, n), np.float32) if True else None
+            if ndev > 1:
+                U_host = dU0.download((n, n), np.float32)
             _log(verbose, f"Left multiplied Y, W by U.T - {time.time() - t1:.3f} s")
+        except BaseException:
+            ectx.close()
+            raise
     else:
         eigenVals = np.maximum(0.0, K).astype(np.float32).reshape(-1)   # lmm.py:166-167
         if eigenVals.shape[0] != n:
@@ -257,13 +265,18 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
                 json.dump(key, f)
     t2 = time.time()
     yr1 = np.ascontiguousarray(Yr.reshape(-1), np.float32)
-    for dev_id, (a, b) in enumerate(SampleIter(p, ndev)):
-        th = threading.Thread(target=_run_block, args=(dev_id, a, b, n, c, eigenVals, Wr, yr1, X, U_host, grid, eigen,
-                                                       out, errs, verbose, checkpoint))
-        th.start()
-        threads.append(th)
-    for th in threads:
-        th.join()
+    try:
+        for dev_id, (a, b) in enumerate(SampleIter(p, ndev)):
+            th = threading.Thread(target=_run_block, args=(dev_id, a, b, n, c, eigenVals, Wr, yr1, X,
+                                                           dU0 if (dev_id == 0 and dU0 is not None) else U_host, grid, eigen,
+                                                           out, errs, verbose, checkpoint))
+            th.start()
+            threads.append(th)
+        for th in threads:
+            th.join()
+    finally:
+        if ectx is not None:
+            ectx.close()
     if errs:
         raise errs[0]
     _log(verbose, f"Finished testing {p} SNPs in {time.time() - t2:.3f} s")
