@@ -73,9 +73,17 @@ def test_drop_in_import_path():
     from pygemma import lmm
     import inspect
     sig = inspect.signature(lmm.pygemma)
-    assert list(sig.parameters) == ["Y", "X", "W", "K", "Z", "snps", "verbose", "disable_checks", "de", "grid", "eigen", "nproc"]
+    ref = ["Y", "X", "W", "K", "Z", "snps", "verbose", "disable_checks", "de", "grid", "eigen", "nproc"]      # lmm/lmm.py:87
+    names = list(sig.parameters)
+    assert names[:len(ref)] == ref              # positional order and names of the reference, so every reference call site works
+    assert names[len(ref):] == ["checkpoint"]   # the one extension (restartable runs): keyword, default off
     d = {k: v.default for k, v in sig.parameters.items() if v.default is not inspect._empty}
-    assert d == {"Z": None, "snps": None, "verbose": 0, "disable_checks": True, "de": False, "grid": False, "eigen": True, "nproc": 1}
+    assert d == {"Z": None, "snps": None, "verbose": 0, "disable_checks": True, "de": False, "grid": False, "eigen": True, "nproc": 1,
+                 "checkpoint": None}
+    for name in ("precompute_mat", "calc_lambda_restricted", "calc_beta_vg_ve_restricted_overload", "newton",
+                 "likelihood_restricted_lambda_overload", "likelihood_derivative1_restricted_lambda_overload",
+                 "likelihood_derivative2_restricted_lambda_overload"):                                   # tests/test_pygemma.py:256-294
+        assert callable(getattr(lmm, name))
 
 
 def test_packed_bed_roundtrip(tmp_path):
