@@ -24,12 +24,13 @@ constexpr int NB = 64;  // reflectors per panel
 static int alloc_d(double **p, size_t count);
 
 // ---------------------------------------------------------------------------------------------
-__global__ void sym_from_lower_kernel(long long n, const float *K, double *A)
+// A (N x N fp64, full symmetric) from the lower triangle of K (n x n float32); N = n or n + 1: the extra row/column is zero
+__global__ void sym_from_lower_kernel(long long n, long long N, const float *K, double *A)
 {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * n) return;
-    long long i = idx / n, j = idx % n;
-    A[idx] = (double)(i >= j ? K[i * n + j] : K[j * n + i]);
+    if (idx >= N * N) return;
+    long long i = idx / N, j = idx % N;
+    A[idx] = (i < n && j < n) ? (double)(i >= j ? K[i * n + j] : K[j * n + i]) : 0.0;
 }
 
 __device__ __forceinline__ double block_sum(double v, double *sh)
@@ -808,7 +809,7 @@ extern "C" int pgx_sytrd_dev(pg_ctx *ctx, int64_t n64, const float *K, double *d
     for (int k = 0; k < 10 && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
     w.Vall = Vall; w.d = d; w.e = e; w.tau = tau;
     if (!rc) {
-        sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, ctx->stream>>>(n, K, w.A);
+        sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, ctx->stream>>>(n, n, K, w.A);
         (void)hipMemsetAsync(w.Vall, 0, (size_t)n * n * 8, ctx->stream);   // rows <= i of reflector i are never written
         rc = sytrd_device(ctx, n, w);
     }
@@ -866,10 +867,15 @@ __global__ __launch_bounds__(64) void larft_kernel(int m, const double *G, const
     for (int j = 0; j < NB; j++) if (i < NB) T[(size_t)i * BB + j] = Ts[i][j];
 }
 
-__global__ void finalize_kernel(long long n, const double *X, const double *ev, float *U32, float *ev32)
+// leading n x n block of X (row stride N) and the first n eigenvalues -> float32 / float64 outputs
+__global__ void finalize_kernel(long long n, long long N, const double *X, const double *ev, float *U32, float *ev32, double *U64)
 {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n * n && U32) U32[idx] = (float)X[idx];
+    if (idx < n * n) {
+        const double x = X[(idx / n) * N + idx % n];
+        if (U32) U32[idx] = (float)x;
+        if (U64) U64[idx] = x;
+    }
     if (idx < n && ev32) ev32[idx] = (float)fmax(ev[idx], 0.0);   // lmm.py:157 np.maximum(0.0, eigenVals), then float32
 }
 
@@ -907,9 +913,13 @@ static int backtransform_device(pg_ctx *ctx, int n, const double *Vall, const do
 extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *evals, float *U, double *evals64, double *U64)
 {
     PG_REQUIRE(ctx && K && (evals || evals64), "pg_syevd_dev: NULL argument");
-    PG_REQUIRE(n64 >= 1 && n64 <= 65536, "pg_syevd_dev: n=%lld out of range", (long long)n64);
+    PG_REQUIRE(n64 >= 1 && n64 <= 65535, "pg_syevd_dev: n=%lld out of range", (long long)n64);
     PG_HIP(hipSetDevice(ctx->device));
-    const int n = (int)n64;
+    const int n0 = (int)n64;
+    // Odd n: work on N = n + 1 with a zero extra row/column.  It stays exactly decoupled through the reduction (v and w
+    // have a zero there), its diagonal entry of T is then set above every other eigenvalue, so it comes out last with
+    // eigenvector e_N and is dropped — and the even-n symmetric symv (half the HBM bytes, 16-byte loads) serves every n.
+    const int n = (n0 > 1 && (n0 & 1)) ? n0 + 1 : n0;
     hipStream_t st = ctx->stream;
     SytrdWork w;
     StedcWork wk;
@@ -933,28 +943,33 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
     double *Z = nullptr;
     if (n == 1) {
         // trivial: T = K
-        sym_from_lower_kernel<<<1, 256, 0, st>>>(1, K, w.A);
+        sym_from_lower_kernel<<<1, 256, 0, st>>>(1, 1, K, w.A);
         if (hipMemcpyAsync(hd.data(), w.A, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = PG_EHIP;
     } else {
         PG_HIP(hipMemsetAsync(w.Vall, 0, (size_t)n * n * 8, st));
         PG_HIP(hipMemsetAsync(w.tau, 0, (size_t)n * 8, st));
-        sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n, K, w.A);
+        sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n0, n, K, w.A);
         rc = sytrd_device(ctx, n, w);
         if (!rc) {
             if (hipMemcpyAsync(hd.data(), w.d, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(he.data(), w.e, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess) { set_error("pg_syevd_dev: reading T back failed: %s", hipGetErrorString(hipGetLastError())); rc = PG_EHIP; }
         }
+        if (!rc && n != n0) {
+            if (he[n - 2] != 0.0) { set_error("pg_syevd_dev: padding row did not stay decoupled (e = %g)", he[n - 2]); rc = PG_EHIP; }
+            double top = 0.0;   // Gershgorin bound of the leading n0 x n0 tridiagonal
+            for (int i = 0; i < n0; i++) top = std::max(top, hd[i] + (i > 0 ? fabs(he[i - 1]) : 0.0) + (i + 1 < n0 ? fabs(he[i]) : 0.0));
+            hd[n - 1] = top + std::max(1.0, fabs(top));
+        }
     }
     if (!rc) rc = stedc_device(ctx, n, hd.data(), he.data(), ev, wk, &Z);
     if (!rc && n > 1) rc = backtransform_device(ctx, n, w.Vall, w.tau, Z, G, T, W, W2);
     if (!rc) {
-        hipError_t e1 = hipMemcpyAsync(dev_ev, ev.data(), (size_t)n * 8, hipMemcpyHostToDevice, st);
+        hipError_t e1 = hipMemcpyAsync(dev_ev, ev.data(), (size_t)n0 * 8, hipMemcpyHostToDevice, st);
         if (e1 != hipSuccess) rc = PG_EHIP;
         if (!rc) {
-            finalize_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n, Z, dev_ev, U, evals);
-            if (evals64 && hipMemcpyAsync(evals64, dev_ev, (size_t)n * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = PG_EHIP;
-            if (U64 && hipMemcpyAsync(U64, Z, (size_t)n * n * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = PG_EHIP;
+            finalize_kernel<<<(unsigned)(((size_t)n0 * n0 + 255) / 256), 256, 0, st>>>(n0, n, Z, dev_ev, U, evals, U64);
+            if (evals64 && hipMemcpyAsync(evals64, dev_ev, (size_t)n0 * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = PG_EHIP;
             if (hipGetLastError() != hipSuccess) rc = PG_EHIP;
         }
         if (rc == PG_EHIP) set_error("pg_syevd_dev: output stage failed");
