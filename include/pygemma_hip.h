@@ -115,6 +115,12 @@ size_t pg_geno_work_bytes(int64_t n, int64_t p);
 int pg_geno_prep_dev(pg_ctx *ctx, int64_t n, const float *U, int64_t ldU, void *Uprep);
 int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const float *X_n_by_p, int64_t ldX, float *Xr,
                        int64_t ldx, void *work, int *is_geno);
+/* The same for X stored as 8-bit integers (int8 / uint8 genotype matrices; the reference casts any dtype to float32,
+ * lmm/lmm.py:121-122, so the values are identical): 4x fewer bytes to upload and to scan.  pg_cast_i8_f32_dev makes the
+ * float32 image a block needs when it does not qualify (then pg_rotate_dev as usual). */
+int pg_rotate_geno_i8_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const void *X8_n_by_p, int is_unsigned, int64_t ldX,
+                          float *Xr, int64_t ldx, void *work, int *is_geno);
+int pg_cast_i8_f32_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *X8_n_by_p, int is_unsigned, int64_t ldX, float *Xf, int64_t ldXf);
 /* The same rotation straight from a PLINK .bed block (the format the reference's callers read with pysnptools.Bed,
  * experiments/benchmarks/benchmarks.py:233-239): bed = device copy of p SNP records of ldb >= ceil(n/4) bytes (SNP-major,
  * 2 bits per sample: 00 hom A1, 01 missing, 10 het, 11 hom A2).  Dosage = copies of A2 (count_a1 = 0, pysnptools

@@ -123,7 +123,8 @@ __global__ void minmax_init_kernel(long long p, int *kmin, int *kmax, int *other
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g < p) { kmin[g] = 0x7FFFFFFF; kmax[g] = (int)0x80000000; other[g] = OTHER_EMPTY; }
 }
-__global__ __launch_bounds__(256) void minmax_geno_kernel(long long n, long long p, const float *X, long long ldX, int *kmin, int *kmax, int *flag)
+template <class T>
+__global__ __launch_bounds__(256) void minmax_geno_kernel(long long n, long long p, const T *X, long long ldX, int *kmin, int *kmax, int *flag)
 {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const long long g = (long long)blockIdx.x * 64 + tx;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void minmax_geno_kernel(long long n, long long
     int lo = 0x7FFFFFFF, hi = (int)0x80000000;
     bool bad = false;
     for (long long i = i0 + ty; i < i0 + 256 && i < n; i += 4) {
-        const float x = X[i * ldX + g];
+        const float x = (float)X[i * ldX + g];
         if (!(fabsf(x) <= 3.0e38f)) bad = true;
         const int k = f2key(x);
         lo = k < lo ? k : lo; hi = k > hi ? k : hi;
@@ -141,7 +142,8 @@ __global__ __launch_bounds__(256) void minmax_geno_kernel(long long n, long long
     atomicMin(&kmin[g], lo);
     atomicMax(&kmax[g], hi);
 }
-__global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long p, const float *X, long long ldX, const int *kmin, const int *kmax,
+template <class T>
+__global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long p, const T *X, long long ldX, const int *kmin, const int *kmax,
                                                           int *other, unsigned short *Gt, long long ldk, int *flag)
 {
     __shared__ unsigned short tile[32][34];
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long
         const long long i = i0 + r;
         unsigned short code = 0;
         if (i < n && g < p) {
-            const float x = X[i * ldX + g];
+            const float x = (float)X[i * ldX + g];
             if (x == lo) code = 0;
             else if (x == hv) code = 0x4000;                       // fp16 2.0
             else if (fabsf(x - mid) <= tol) code = 0x3C00;         // fp16 1.0
@@ -177,7 +179,8 @@ __global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long
     }
 }
 // indicator plane (fp16 0/1) of the columns' other value, SNP-major like Gt; only run for blocks that have one
-__global__ __launch_bounds__(256) void indicator_geno_kernel(long long n, long long p, const float *X, long long ldX, const int *other,
+template <class T>
+__global__ __launch_bounds__(256) void indicator_geno_kernel(long long n, long long p, const T *X, long long ldX, const int *other,
                                                              unsigned short *Gi, long long ldk)
 {
     __shared__ unsigned short tile[32][34];
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256) void indicator_geno_kernel(long long n, long l
     const int ob = (g < p) ? other[g] : OTHER_EMPTY;
     for (int r = ty; r < 32; r += 8) {
         const long long i = i0 + r;
-        tile[r][tx] = (i < n && g < p && ob != OTHER_EMPTY && __float_as_int(X[i * ldX + g]) == ob) ? 0x3C00 : 0;
+        tile[r][tx] = (i < n && g < p && ob != OTHER_EMPTY && __float_as_int((float)X[i * ldX + g]) == ob) ? 0x3C00 : 0;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
@@ -235,6 +238,14 @@ __global__ __launch_bounds__(256) void decode_bed_kernel(long long n, long long 
         dlt[g] = (cnt[2] > 0 && called > 0) ? (float)(((double)cnt[0] + 2.0 * (double)cnt[1]) / called) : 0.0f;
         if (cnt[2] > 0) atomicOr(flag + 1, 1);
     }
+}
+
+template <class T>
+__global__ void cast_to_f32_kernel(long long n, long long p, const T *X, long long ldX, float *Xf, long long ldXf)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p) return;
+    for (long long i = blockIdx.y; i < n; i += gridDim.y) Xf[i * ldXf + g] = (float)X[i * ldX + g];
 }
 
 struct GenoParams {
@@ -475,8 +486,9 @@ extern "C" size_t pg_geno_work_bytes(int64_t n, int64_t p)
     const long long ldk = (n + GBK - 1) / GBK * GBK;
     return 2 * (((size_t)p * ldk * 2 + 255) & ~(size_t)255) + (size_t)p * 24 + 512;   // codes, indicator plane, v0/dx/delta/min/max/other
 }
-extern "C" int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const float *X, int64_t ldX, float *Xr, int64_t ldx,
-                                  void *work, int *is_geno_host)
+template <class T>
+static int rotate_geno_any(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const T *X, int64_t ldX, float *Xr, int64_t ldx,
+                           void *work, int *is_geno_host)
 {
     PG_REQUIRE(ctx && Uprep && X && Xr && work && is_geno_host, "pg_rotate_geno_dev: NULL argument");
     PG_REQUIRE(n > 0 && p > 0 && ldX >= p && ldx >= n && ldx <= (n + 127) / 128 * 128, "pg_rotate_geno_dev: bad shape");
@@ -490,8 +502,8 @@ extern "C" int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void 
     int *flag = other + p;           // flag[0]: not a genotype block; flag[1]: some column holds an other (imputed) value
     PG_HIP(hipMemsetAsync(flag, 0, 8, ctx->stream));
     minmax_init_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, other);
-    minmax_geno_kernel<<<dim3((unsigned)((p + 63) / 64), (unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, flag);
-    encode_geno_kernel<<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk, flag);
+    minmax_geno_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, flag);
+    encode_geno_kernel<T><<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk, flag);
     params_geno_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, other, v0, dx, dlt);
     PG_HIP(hipGetLastError());
     int hflag[2] = {0, 0};
@@ -500,8 +512,35 @@ extern "C" int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void 
     *is_geno_host = hflag[0] ? 0 : 1;
     if (hflag[0]) return PG_OK;
     if (hflag[1])
-        indicator_geno_kernel<<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk);
+        indicator_geno_kernel<T><<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk);
     return launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, hflag[1] != 0);
+}
+
+extern "C" int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const float *X, int64_t ldX, float *Xr, int64_t ldx,
+                                  void *work, int *is_geno_host)
+{
+    return rotate_geno_any<float>(ctx, n, p, Uprep, X, ldX, Xr, ldx, work, is_geno_host);
+}
+
+// The same for X held as 8-bit integers (genotype matrices are often stored that way; the reference casts any dtype to
+// float32, lmm/lmm.py:121-122, so the values are the same): 4x fewer bytes to upload and to scan.
+extern "C" int pg_rotate_geno_i8_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const void *X8, int is_unsigned, int64_t ldX,
+                                     float *Xr, int64_t ldx, void *work, int *is_geno_host)
+{
+    return is_unsigned ? rotate_geno_any<unsigned char>(ctx, n, p, Uprep, (const unsigned char *)X8, ldX, Xr, ldx, work, is_geno_host)
+                       : rotate_geno_any<signed char>(ctx, n, p, Uprep, (const signed char *)X8, ldX, Xr, ldx, work, is_geno_host);
+}
+
+// float32 image of an 8-bit block (the fallback input of pg_rotate_dev / pg_transpose_dev for blocks that do not qualify)
+extern "C" int pg_cast_i8_f32_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *X8, int is_unsigned, int64_t ldX, float *Xf, int64_t ldXf)
+{
+    PG_REQUIRE(ctx && X8 && Xf && n > 0 && p > 0 && ldX >= p && ldXf >= p, "pg_cast_i8_f32_dev: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((p + 255) / 256), (unsigned)(n < 65535 ? n : 65535));
+    if (is_unsigned) cast_to_f32_kernel<unsigned char><<<grid, 256, 0, ctx->stream>>>(n, p, (const unsigned char *)X8, ldX, Xf, ldXf);
+    else cast_to_f32_kernel<signed char><<<grid, 256, 0, ctx->stream>>>(n, p, (const signed char *)X8, ldX, Xf, ldXf);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
 }
 
 // Rotate a block of PLINK .bed genotypes (device copy of the packed bytes: p rows of ldb >= ceil(n/4) bytes, SNP-major as in

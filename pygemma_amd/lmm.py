@@ -90,9 +90,11 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
                 _lib.check(L.pg_geno_prep_dev(ctx0.handle, n, dU.ptr, n, dprep.ptr), "pg_geno_prep_dev")
             ctx0.sync()
             packed = isinstance(X, PackedBed)
+            x8 = (not packed) and X.dtype in (np.int8, np.uint8)
+            esz = 1 if x8 else 4
             pb_max = max(256, int(_BATCH_BYTES // (12 * ldx)) // 256 * 256)   # raw block + rotated block + two fp16 planes
             pb_max = min(pb_max, _BATCH_SNPS, b - a)
-            ldX = (pb_max + 3) // 4 * 4
+            ldX = (pb_max + 15) // 16 * 16
             bpr = (n + 3) // 4
             p = X.shape[1]
             todo = []
@@ -111,7 +113,8 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
                 try:
                     ctx = _lib.Context(device)
                     try:
-                        dX = ctx.alloc(pb_max * bpr if packed else n * ldX * 4)
+                        dX = ctx.alloc(pb_max * bpr if packed else n * ldX * esz)
+                        dXf = None       # float32 image of an 8-bit block, only if one does not qualify for the genotype path
                         dXr = ctx.alloc(pb_max * ldx * 4)
                         dout, dF = ctx.alloc(pb_max * 16), ctx.alloc(pb_max * 16)
                         dwork = ctx.alloc(L.pg_geno_work_bytes(n, pb_max)) if eigen else None
@@ -127,9 +130,18 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
                                 _lib.check(L.pg_rotate_bed_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, bpr, int(X.count_A1), dXr.ptr, ldx,
                                                                dwork.ptr), "pg_rotate_bed_dev")
                             else:
-                                _lib.check(L.pg_memcpy2d_h2d(ctx.handle, dX.ptr, ldX * 4, X.ctypes.data + 4 * s, p * 4, pb * 4, n),
+                                _lib.check(L.pg_memcpy2d_h2d(ctx.handle, dX.ptr, ldX * esz, X.ctypes.data + esz * s, p * esz, pb * esz, n),
                                            "pg_memcpy2d_h2d")
-                                if eigen:
+                                if x8:
+                                    is_geno = C.c_int(0)
+                                    _lib.check(L.pg_rotate_geno_i8_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, int(X.dtype == np.uint8), ldX,
+                                                                       dXr.ptr, ldx, dwork.ptr, C.byref(is_geno)), "pg_rotate_geno_i8_dev")
+                                    if not is_geno.value:
+                                        dXf = dXf or ctx.alloc(n * ldX * 4)
+                                        _lib.check(L.pg_cast_i8_f32_dev(ctx.handle, n, pb, dX.ptr, int(X.dtype == np.uint8), ldX, dXf.ptr, ldX),
+                                                   "pg_cast_i8_f32_dev")
+                                        _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dXf.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
+                                elif eigen:
                                     is_geno = C.c_int(0)
                                     _lib.check(L.pg_rotate_geno_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx, dwork.ptr,
                                                                     C.byref(is_geno)), "pg_rotate_geno_dev")
@@ -193,7 +205,8 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
         Y = Y.astype(np.float32).reshape(-1, 1)              # lmm.py:115-116
     if W.dtype != np.float32:
         W = W.astype(np.float32)                             # lmm.py:118-119
-    if not packed and X.dtype != np.float32:
+    x8 = (not packed) and eigen and X.dtype in (np.int8, np.uint8)   # stays 8-bit up to the device: same values as the cast below
+    if not packed and not x8 and X.dtype != np.float32:
         X = X.astype(np.float32)                             # lmm.py:121-122
     if Z is not None:
         K = np.asarray(Z) @ K @ np.asarray(Z).T              # lmm.py:124-125
@@ -243,7 +256,7 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     if not disable_checks:
         # lmm.py:253-256 (the reference tests the rotated arrays; a NaN anywhere in a raw column makes that
         # whole rotated column NaN, so testing the inputs raises in exactly the same cases)
-        if (not packed and np.isnan(X).any()) or np.isnan(Yr).any() or np.isnan(Wr).any():
+        if (not packed and not x8 and np.isnan(X).any()) or np.isnan(Yr).any() or np.isnan(Wr).any():
             raise ValueError("NaNs present in data")
 
     _log(verbose, f"Running {p} SNPs with {n} individuals on {ndev} GPU(s)...")

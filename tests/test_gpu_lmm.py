@@ -137,3 +137,26 @@ def test_checkpoint_restart(tmp_path, monkeypatch):
     assert (b["beta"].to_numpy()[512:] == ref["beta"].to_numpy()[512:]).all()
     with pytest.raises(ValueError):
         lmm.pygemma(Y, X[:, :700], W, d, eigen=False, checkpoint=ck)
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.uint8])
+def test_pygemma_int8_genotypes_match_float_input(dtype):
+    """8-bit genotype matrices go to the device as they are (the reference would cast them to float32 first, lmm.py:121-122):
+    same results as the float32 call; a block that is not genotype-valued (0..5 dosages) takes the cast + fp32 path."""
+    from pygemma_amd import lmm, synth
+    rng = np.random.default_rng(21)
+    n, p, c = 257, 600, 2
+    G = rng.binomial(2, rng.uniform(0.05, 0.5, p), size=(n, p)).astype(dtype)
+    GK = synth.genotypes(rng, n, 2 * n)
+    K = (GK @ GK.T / (2 * n)).astype(np.float32)
+    W = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, c - 1))], axis=1).astype(np.float32)
+    y = (0.3 * G[:, 0] + rng.standard_normal(n)).astype(np.float32).reshape(-1, 1)
+    a = lmm.pygemma(y, G, W, K)
+    b = lmm.pygemma(y, G.astype(np.float32), W, K)
+    for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
+        assert (a[col].to_numpy() == b[col].to_numpy()).all(), col     # same codes, same planes, same kernel: identical
+    G2 = rng.integers(0, 6, size=(n, p)).astype(dtype)                   # not genotype-valued
+    a = lmm.pygemma(y, G2, W, K)
+    b = lmm.pygemma(y, G2.astype(np.float32), W, K)
+    for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
+        assert (a[col].to_numpy() == b[col].to_numpy()).all(), col
