@@ -146,14 +146,16 @@ template <class T>
 __global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long p, const T *X, long long ldX, const int *kmin, const int *kmax,
                                                           int *other, unsigned short *Gt, long long ldk, int *flag)
 {
-    __shared__ unsigned short tile[32][34];
-    const long long g0 = (long long)blockIdx.x * 32, i0 = (long long)blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    // tile: 64 SNPs x 128 samples — 256-byte row segments on the way in (64 floats) and on the way out (128 fp16 codes)
+    __shared__ unsigned short tile[128][66];
+    const long long g0 = (long long)blockIdx.x * 64, i0 = (long long)blockIdx.y * 128;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const long long g = g0 + tx;
     const float lo = (g < p) ? key2f(kmin[g]) : 0.0f, hv = (g < p) ? key2f(kmax[g]) : 0.0f;
     const float mid = lo + 0.5f * (hv - lo), tol = 8.0f * 1.1920929e-7f * fmaxf(fabsf(lo), fabsf(hv));
     bool bad = false, any_ind = false;
-    for (int r = ty; r < 32; r += 8) {
+#pragma unroll 8
+    for (int r = ty; r < 128; r += 4) {
         const long long i = i0 + r;
         unsigned short code = 0;
         if (i < n && g < p) {
@@ -173,11 +175,14 @@ __global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long
     if (bad) atomicOr(flag, 1);
     if (any_ind) atomicOr(flag + 1, 1);
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const long long gg = g0 + r, i = i0 + tx;
-        if (gg < p && i < ldk) Gt[gg * ldk + i] = tile[tx][r];
+    // thread -> two consecutive samples of one SNP row: 64 threads x 4 bytes = one 256-byte segment
+    for (int r = ty; r < 64; r += 4) {
+        const long long gg = g0 + r, i = i0 + 2 * tx;
+        if (gg < p && i < ldk)     // ldk is a multiple of 64: i even and i < ldk  =>  i + 1 < ldk
+            *reinterpret_cast<unsigned *>(Gt + gg * ldk + i) = (unsigned)tile[2 * tx][r] | ((unsigned)tile[2 * tx + 1][r] << 16);
     }
 }
+
 // indicator plane (fp16 0/1) of the columns' other value, SNP-major like Gt; only run for blocks that have one
 template <class T>
 __global__ __launch_bounds__(256) void indicator_geno_kernel(long long n, long long p, const T *X, long long ldX, const int *other,
@@ -503,7 +508,7 @@ static int rotate_geno_any(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep,
     PG_HIP(hipMemsetAsync(flag, 0, 8, ctx->stream));
     minmax_init_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, other);
     minmax_geno_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, flag);
-    encode_geno_kernel<T><<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk, flag);
+    encode_geno_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((ldk + 127) / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk, flag);
     params_geno_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, other, v0, dx, dlt);
     PG_HIP(hipGetLastError());
     int hflag[2] = {0, 0};
