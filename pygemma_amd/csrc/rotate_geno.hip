@@ -19,9 +19,8 @@
 //
 // Layout: both operands K-contiguous ("NT" GEMM): Gt [p][ldk] fp16 codes (SNP-major), Up [n][2*KT*GBK] fp16 with the
 // two planes of each 64-sample K-tile interleaved, so the kernel is a plain GEMM over K' = 2K whose A tile index is
-// kt'/2.  256 (SNPs) x 128 (eigen index) tile per 512-thread workgroup, 8 waves as 4x2, each 64x64 = 4x4
-// v_mfma_f32_16x16x32_f16 tiles (the 16x16x32 shape sustains a higher clock than 32x32x16 at equal cycles per flop),
-// BK = 64, operands staged by LDS-DMA into an XOR-swizzled ring (see rotate_geno_kernel).
+// kt'/2.  256 x 256 tile per 512-thread workgroup (v_mfma_f32_16x16x32_f16: the 16x16x32 shape sustains a higher clock than
+// 32x32x16 at equal cycles per flop), BK = 64, operands staged by LDS-DMA into XOR-swizzled LDS rings (see rotate_geno_kernel).
 #include "common.hpp"
 
 namespace pg {
@@ -32,7 +31,7 @@ typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 #ifndef PG_GBK
 #define PG_GBK 64
 #endif
-constexpr int GBM = 256, GBN = 128, GBK = PG_GBK;
+constexpr int GBM = 256, GBN = 256, GBK = PG_GBK;
 static_assert(GBK == 64, "the LDS image is 128-byte rows: 64 fp16 per K-tile");
 
 __device__ __forceinline__ unsigned short f32_to_f16_rn(float f)
@@ -269,27 +268,26 @@ struct GenoParams {
 // read address, so the 16 rows a ds_read_b128 lane group touches fall on 16 different bank quads.
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-// Staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of THREE U-plane
-// buffers (128 rows; stage t = plane t&1 of K-tile t>>1 lives in B[t%3]) and THREE genotype buffers (256 rows; K-tile T in
-// A[T%3]), with the DMA of stage t+2 / of K-tile T+2 in flight across the barriers of stage t.  Waits are counted
+// The GEMM.  256 x 256 tile per 512-thread workgroup, 8 waves as 4 x 2, each 64 (SNPs) x 128 (eigen indices) = 4 x 8
+// v_mfma_f32_16x16x32_f16 tiles; K-tile 64; stage t = U plane t&1 of K-tile t>>1 (K' = 2K).
+// Staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into two genotype buffers + three
+// U-plane buffers of 32 KB = 160 KB of LDS, DMA for stage t+2 in flight across the barriers of stage t.  Waits are counted
 // (`s_waitcnt vmcnt(#issued this stage)` retires everything older) and the barriers are raw s_barrier: __syncthreads()
-// would drain the DMA at every barrier.  Every stage issues the same four DMA instructions per wave (two for the U plane
-// two stages ahead, two for half of the wave's share of the genotype tile two K-tiles ahead): a stage that issues more
-// than its MFMA phase can cover stalls both waves of the SIMD at the next barrier (measured on the 2-buffer version:
-// 2+6 instructions per K-tile cost 3x what 2+2 or 0+4 cost).
-//
-// Ping-pong: waves 0-3 ("early") and 4-7 ("late") sit one per SIMD and run half a stage apart, so that while one wave of
-// a SIMD issues its 32 MFMAs the other issues its DMA and reads its fragments:
-//   phase 2t   : early mem(t)   | late mfma(t-1)
-//   phase 2t+1 : early mfma(t)  | late mem(t)          (one s_barrier between consecutive phases)
-// mem(t) = issue DMA, read the fragments of stage t into registers, wait until the own share of everything issued before
-// this stage has landed.  B[(t+2)%3] was last read in mem(t-1) (a barrier ago); A[(T+2)%3] at plane 0 of K-tile T-1.
-// The genotype fragments live in registers for both planes of a K-tile.
+// would drain the DMA at every barrier.
+// Ping-pong: waves 0-3 ("early") and 4-7 ("late") sit one per SIMD (workgroup waves go to SIMDs round-robin) and run half
+// a stage apart: while one wave of a SIMD issues its 64 MFMAs the other issues DMA and reads fragments.  The genotype
+// fragments are read once per K-tile and kept in registers for both planes.  The U fragments of the second k-half are read during the MFMA phase (each replaces
+// its predecessor as soon as that one's MFMAs are issued: 32 fragment registers instead of 64), so a U buffer stays busy
+// through the late waves' MFMA phase; the DMA duties are therefore split by group: the LATE waves stage the whole U plane
+// (8 instructions per wave and stage, issued in their memory phase, i.e. after their own last read of the buffer they
+// refill), the EARLY waves stage the genotype tile (4 per wave and stage), each group with its own counted wait.
+//   phase 2t   : early mem(t)   [A half of tile T+1|T+2; reads] | late mfma(t-1) [rolling reads of B[(t-1)%3]]
+//   phase 2t+1 : early mfma(t)                                  | late mem(t)    [B(t+2) -> B[(t-1)%3]; reads]
 __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 {
-    constexpr int BBUF = 128 * 128, ABUF = 256 * 128;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * BBUF + 3 * ABUF];
-    unsigned char *const Bs = lds, *const As = lds + 3 * BBUF;
+    constexpr int TBUF = 256 * 128;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char *const Bs = lds, *const As = lds + 3 * TBUF;
     const int T = gp.tiles_m * gp.tiles_n;
     const int b = blockIdx.x;
     const int q = T / 8, r = T % 8, xcd = b % 8;
@@ -298,125 +296,126 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
     const int grp = lid / per_group, first_m = grp * 4;
     const int gsz = (gp.tiles_m - first_m) < 4 ? (gp.tiles_m - first_m) : 4;
     const int tm = first_m + (lid % per_group) % gsz, tn = (lid % per_group) / gsz;
-    const long long m0 = (long long)tm * GBM, n0 = (long long)tn * GBN;
+    const long long m0 = (long long)tm * 256, n0 = (long long)tn * 256;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves, each 64 (SNPs) x 128 (eigen indices)
     const int KT2 = 2 * gp.KT;
 
-    floatx4 acc[4][4];
+    floatx4 acc[4][8];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < 8; j++)
 #pragma unroll
             for (int e = 0; e < 4; e++) acc[i][j][e] = 0.0f;
 
-    // wave w fills rows 32w .. 32w+31 of a genotype tile and rows 16w .. 16w+15 of a U-plane tile, 8 rows per DMA
-    // instruction; rows past the end of the operand are clamped (their outputs are never stored)
-    const int lrow = lane >> 3, lchunk = lane & 7;
-    const unsigned char *gA[4], *gB[2];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const int row = wave * 32 + 8 * t + lrow;
-        long long rm = m0 + row;
-        rm = rm < gp.p ? rm : gp.p - 1;
-        gA[t] = reinterpret_cast<const unsigned char *>(gp.Gt + rm * gp.ldk) + swz(row, lchunk) * 16;
-    }
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int row = wave * 16 + 8 * t + lrow;
-        long long rn = n0 + row;
-        rn = rn < gp.n ? rn : gp.n - 1;
-        gB[t] = reinterpret_cast<const unsigned char *>(gp.Up + rn * gp.ldp) + swz(row, lchunk) * 16;
-    }
-    auto dmaB = [&](int stage, int buf) {
-        unsigned char *dst = Bs + buf * BBUF + (wave * 16) * 128;
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gB[t] + (size_t)stage * GBK * 2),
-                                             (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
-    };
-    auto dmaA = [&](int ktile, int buf, int half) {       // rows 16*half .. 16*half+15 of this wave's 32 rows
-        unsigned char *dst = As + buf * ABUF + (wave * 32 + 16 * half) * 128;
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gA[2 * half + t] + (size_t)ktile * GBK * 2),
-                                             (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
-    };
-    // prologue: K-tile 0 (genotypes + both planes = stages 0, 1) and the genotypes of K-tile 1; only stage 0's operands
-    // have to have landed at the first barrier
-    dmaA(0, 0, 0); dmaA(0, 0, 1); dmaB(0, 0);
-    dmaB(1, 1);
-    if (gp.KT > 1) { dmaA(1, 1, 0); dmaA(1, 1, 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // early wave w (0..3) fills rows 64w .. 64w+63 of the genotype tile, late wave w (4..7) rows 64(w-4) .. of the U-plane
+    // tile: 8 instructions of 8 rows; rows past the end of the operand are clamped (their outputs are never stored)
     const bool late = wave >= 4;
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    const unsigned char *gsrc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int row = (wave & 3) * 64 + 8 * t + lrow;
+        long long rm = m0 + row, rn = n0 + row;
+        rm = rm < gp.p ? rm : gp.p - 1;
+        rn = rn < gp.n ? rn : gp.n - 1;
+        gsrc[t] = (late ? reinterpret_cast<const unsigned char *>(gp.Up + rn * gp.ldp)
+                        : reinterpret_cast<const unsigned char *>(gp.Gt + rm * gp.ldk)) + swz(row, lchunk) * 16;
+    }
+    auto dmaB = [&](int stage, int buf) {            // late waves only
+        unsigned char *dst = Bs + buf * TBUF + ((wave & 3) * 64) * 128;
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[t] + (size_t)stage * GBK * 2),
+                                             (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
+    };
+    auto dmaA = [&](int ktile, int half) {           // early waves only: rows 32*half .. 32*half+31 of the wave's 64 rows
+        unsigned char *dst = As + (ktile & 1) * TBUF + ((wave & 3) * 64 + 32 * half) * 128;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[4 * half + t] + (size_t)ktile * GBK * 2),
+                                             (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
+    };
+    // prologue: K-tile 0 (genotypes + both planes) and the first half of the genotypes of K-tile 1
+    if (late) {
+        dmaB(0, 0); dmaB(1, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        dmaA(0, 0); dmaA(0, 1);
+        if (gp.KT > 1) { dmaA(1, 0); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
     if (late) __builtin_amdgcn_s_barrier();
-    int a0 = 0, b0 = 0;   // buffers of the current K-tile / stage: T % 3, t % 3
-    halfx8 fa[2][4];      // genotype fragments: read at plane 0 of a K-tile, reused for its second U plane
+    int b0 = 0;
+    halfx8 fa[2][4];
     for (int ktile = 0; ktile < gp.KT; ktile++) {
-      const unsigned char *Acur = As + a0 * ABUF;
-      const int a2 = (a0 >= 1) ? a0 - 1 : 2;              // (T + 2) % 3
+      const unsigned char *Acur = As + (ktile & 1) * TBUF;
 #pragma unroll
       for (int pl = 0; pl < 2; pl++) {
         const int kt = 2 * ktile + pl;
-        const unsigned char *Bcur = Bs + b0 * BBUF;
+        const unsigned char *Bcur = Bs + b0 * TBUF;
         const int b2 = (b0 >= 1) ? b0 - 1 : 2;            // (t + 2) % 3
-        int issued = 0;
-        if (kt + 2 < KT2) {
-            dmaB(kt + 2, b2); issued = 2;
-            if (ktile + 2 < gp.KT) { dmaA(ktile + 2, a2, pl); issued = 4; }
-        }
-        // 16x16x32 operand: lane l holds row (l & 15), k = 32*ks + 8*(l >> 4) .. +7 = logical 16-byte chunk 4*ks + (l >> 4)
-        halfx8 fb[2][4];
+        bool issued = false;
+        // ---------------- memory phase
+        if (late) { if (kt + 2 < KT2) { dmaB(kt + 2, b2); issued = true; } }
+        else if (pl == 0) { if (ktile + 1 < gp.KT) { dmaA(ktile + 1, 1); issued = true; } }   // second half of K-tile T+1
+        else { if (ktile + 2 < gp.KT) { dmaA(ktile + 2, 0); issued = true; } }              // first half of K-tile T+2
+        halfx8 fb[8];
+        const int chunk0 = lane >> 4;
+        if (pl == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            const int chunk = 4 * ks + (lane >> 4);
-            if (pl == 0) {
+            for (int ks = 0; ks < 2; ks++)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int row = wm * 64 + i * 16 + (lane & 15);
-                    fa[ks][i] = *reinterpret_cast<const halfx8 *>(Acur + row * 128 + swz(row, chunk) * 16);
+                    fa[ks][i] = *reinterpret_cast<const halfx8 *>(Acur + row * 128 + swz(row, 4 * ks + chunk0) * 16);
                 }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int row = wn * 64 + j * 16 + (lane & 15);
-                fb[ks][j] = *reinterpret_cast<const halfx8 *>(Bcur + row * 128 + swz(row, chunk) * 16);
-            }
         }
-        if (issued == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int row = wn * 128 + j * 16 + (lane & 15);
+            fb[j] = *reinterpret_cast<const halfx8 *>(Bcur + row * 128 + swz(row, chunk0) * 16);
+        }
+        // everything this wave issued before this stage has landed
+        if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (late) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        // ---------------- MFMA phase
         __builtin_amdgcn_s_setprio(1);
+        // k-half 0 column by column; each U fragment is replaced by its k-half-1 successor as soon as its four MFMAs are
+        // issued (the read hides behind the remaining ones), then k-half 1
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++)
+        for (int j = 0; j < 8; j++) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[j], acc[i][j], 0, 0, 0);
+            const int row = wn * 128 + j * 16 + (lane & 15);
+            fb[j] = *reinterpret_cast<const halfx8 *>(Bcur + row * 128 + swz(row, 4 + chunk0) * 16);
+        }
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][i], fb[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         b0 = (b0 == 2) ? 0 : b0 + 1;
       }
-      a0 = (a0 == 2) ? 0 : a0 + 1;
     }
     if (!late) __builtin_amdgcn_s_barrier();
-    // epilogue: Xr[g][k] = v0_g * (U'1)_k + (dx_g / S) * acc   (fp64 combine, one rounding to fp32); pad columns zero.
-    // Accumulate pass (v0 == nullptr): Xr[g][k] += (dx_g / S) * acc.
     const double invS = (double)gp.scale[1];
     const bool accum = gp.v0 == nullptr;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const long long col = n0 + wn * 64 + j * 16 + (lane & 15);
+        for (int j = 0; j < 8; j++) {
+            const long long col = n0 + wn * 128 + j * 16 + (lane & 15);
             const double ck = (col < gp.n) ? gp.colsum[col] : 0.0;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -472,13 +471,19 @@ static int launch_geno_gemm(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep
     gp.colsum = sums + (size_t)kt * n;
     gp.scale = (const float *)(sums + (size_t)(kt + 1) * n);
     gp.v0 = v0; gp.dx = dx; gp.Xr = Xr;
-    gp.tiles_m = (int)((p + GBM - 1) / GBM); gp.tiles_n = (int)((n + GBN - 1) / GBN); gp.KT = (int)kt;
+    constexpr int WLDS = 5 * 256 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rotate_geno_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
+        attr_set = true;
+    }
+    gp.tiles_m = (int)((p + 255) / 256); gp.tiles_n = (int)((n + 255) / 256); gp.KT = (int)kt;
     const long long T = (long long)gp.tiles_m * gp.tiles_n;
     PG_REQUIRE(T < (1LL << 31), "genotype rotation: too many tiles");
-    rotate_geno_kernel<<<dim3((unsigned)T), 512, 0, ctx->stream>>>(gp);
+    rotate_geno_kernel<<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
     if (second_pass) {   // Xr += delta * U'ind
         gp.Gt = Gi; gp.v0 = nullptr; gp.dx = dlt;
-        rotate_geno_kernel<<<dim3((unsigned)T), 512, 0, ctx->stream>>>(gp);
+        rotate_geno_kernel<<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
     }
     PG_HIP(hipGetLastError());
     return PG_OK;
