@@ -107,9 +107,12 @@ int pg_rotate_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU
  * (same error class as pg_rotate_dev / the reference's sgemm, 8x fewer matrix cycles).  A column may also hold ONE other
  * value anywhere (missing calls imputed with the column mean, experiments/benchmarks/benchmarks.py:243-244): such blocks
  * take a second, accumulating pass on the 0/1 indicator plane.
+ * Finite blocks that are not genotype-valued (imputed dosages, any float X) take the same GEMM with X itself split into two
+ * fp16 planes (per-column power-of-two scale, residual <= 2^-24 |x|): two passes, still 3x faster than pg_rotate_dev.
  *   pg_geno_prep_dev   : once per U -> Uprep (pg_geno_prep_bytes(n) bytes, device)
- *   pg_rotate_geno_dev : per SNP block; *is_geno = 1 and Xr written (same layout as pg_rotate_dev) when every column
- *                        qualifies, else *is_geno = 0 and Xr untouched (call pg_rotate_dev).  Synchronises the stream. */
+ *   pg_rotate_geno_dev : per SNP block; Xr written (same layout as pg_rotate_dev) and *is_geno = 1 (genotype-valued block)
+ *                        or 2 (general finite block, split path); *is_geno = 0 and Xr untouched when the block holds a NaN
+ *                        or Inf (call pg_rotate_dev: its propagation is the reference's).  Synchronises the stream. */
 size_t pg_geno_prep_bytes(int64_t n);
 size_t pg_geno_work_bytes(int64_t n, int64_t p);
 int pg_geno_prep_dev(pg_ctx *ctx, int64_t n, const float *U, int64_t ldU, void *Uprep);

@@ -4,7 +4,12 @@
 //
 //   x_g = v0_g + dx_g * code_g,  code in {0,1,2}   =>   U'x_g = v0_g * (U'1) + dx_g * (U' code_g)
 //
-// A column may in addition hold ONE other value o_g anywhere (missing calls imputed with the column mean — what the
+// Blocks that are NOT genotype-valued (imputed dosages, any finite float X) take the same GEMM with X itself split in two
+// fp16 planes, s_g x = X1 + X2 + e (s_g a per-column power of two, |e| <= 2^-24 |s_g x|): pass 1 on X1 with both U planes,
+// pass 2 accumulates X2 (its H2 part is below 2^-24 and costs nothing to keep).  Only blocks with a NaN/Inf are left to
+// the fp32-MFMA kernel (pg_rotate_dev), whose NaN/Inf propagation is the reference's.
+//
+// A genotype column may in addition hold ONE other value o_g anywhere (missing calls imputed with the column mean — what the
 // reference's callers do before lmm.pygemma, experiments/benchmarks/benchmarks.py:243-244):
 //   x_g = v0_g + dx_g * code_g + (o_g - v0_g) * ind_g   (code 0 where ind = 1)
 // and the block takes a second pass of the same GEMM on the 0/1 indicator plane, accumulated onto the first.
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256) void minmax_geno_kernel(long long n, long long
         const int k = f2key(x);
         lo = k < lo ? k : lo; hi = k > hi ? k : hi;
     }
-    if (bad) atomicOr(flag, 1);
+    if (bad) atomicOr(flag, 2);       // NaN / Inf somewhere in the block
     atomicMin(&kmin[g], lo);
     atomicMax(&kmax[g], hi);
 }
@@ -180,6 +185,54 @@ __global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long
         if (gg < p && i < ldk)     // ldk is a multiple of 64: i even and i < ldk  =>  i + 1 < ldk
             *reinterpret_cast<unsigned *>(Gt + gg * ldk + i) = (unsigned)tile[2 * tx][r] | ((unsigned)tile[2 * tx + 1][r] << 16);
     }
+}
+
+// general float columns: s x = X1 + X2 (two fp16 planes, round to nearest twice), s = the power of two that puts the
+// column's largest magnitude in [2^14, 2^15); SNP-major planes like Gt
+__device__ __forceinline__ float split_scale(float lo, float hv)
+{
+    const float m = fmaxf(fabsf(lo), fabsf(hv));
+    if (!(m > 0.0f)) return 1.0f;
+    int e = (int)((__float_as_uint(m) >> 23) & 0xFF);          // biased exponent (subnormal maxima: e = 0 -> clamp below)
+    int se = 127 + 14 - (e - 127);
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    return __int_as_float(se << 23);
+}
+template <class T>
+__global__ __launch_bounds__(256) void split_x_kernel(long long n, long long p, const T *X, long long ldX, const int *kmin, const int *kmax,
+                                                      unsigned short *X1, unsigned short *X2, long long ldk)
+{
+    __shared__ unsigned short t1[128][66], t2[128][66];
+    const long long g0 = (long long)blockIdx.x * 64, i0 = (long long)blockIdx.y * 128;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long g = g0 + tx;
+    const float sc = (g < p) ? split_scale(key2f(kmin[g]), key2f(kmax[g])) : 1.0f;
+#pragma unroll 8
+    for (int r = ty; r < 128; r += 4) {
+        const long long i = i0 + r;
+        unsigned short h1 = 0, h2 = 0;
+        if (i < n && g < p) {
+            const float x = (float)X[i * ldX + g] * sc;          // exact: power of two
+            h1 = f32_to_f16_rn(x);
+            h2 = f32_to_f16_rn(x - f16_to_f32(h1));
+        }
+        t1[r][tx] = h1; t2[r][tx] = h2;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const long long gg = g0 + r, i = i0 + 2 * tx;
+        if (gg < p && i < ldk) {
+            *reinterpret_cast<unsigned *>(X1 + gg * ldk + i) = (unsigned)t1[2 * tx][r] | ((unsigned)t1[2 * tx + 1][r] << 16);
+            *reinterpret_cast<unsigned *>(X2 + gg * ldk + i) = (unsigned)t2[2 * tx][r] | ((unsigned)t2[2 * tx + 1][r] << 16);
+        }
+    }
+}
+__global__ void params_split_kernel(long long p, const int *kmin, const int *kmax, float *v0, float *dx, float *dlt)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p) return;
+    const float inv = 1.0f / split_scale(key2f(kmin[g]), key2f(kmax[g]));   // exact
+    v0[g] = 0.0f; dx[g] = inv; dlt[g] = inv;
 }
 
 // indicator plane (fp16 0/1) of the columns' other value, SNP-major like Gt; only run for blocks that have one
@@ -519,8 +572,15 @@ static int rotate_geno_any(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep,
     int hflag[2] = {0, 0};
     PG_HIP(hipMemcpyAsync(hflag, flag, 8, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
-    *is_geno_host = hflag[0] ? 0 : 1;
-    if (hflag[0]) return PG_OK;
+    if (hflag[0] & 2) { *is_geno_host = 0; return PG_OK; }     // NaN / Inf: the fp32 kernel's propagation is the reference's
+    if (hflag[0] & 1) {                                        // finite, not genotype-valued: X itself in two fp16 planes
+        *is_geno_host = 2;
+        split_x_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((ldk + 127) / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, Gt, Gi, ldk);
+        params_split_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, v0, dx, dlt);
+        PG_HIP(hipGetLastError());
+        return launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, true);
+    }
+    *is_geno_host = 1;
     if (hflag[1])
         indicator_geno_kernel<T><<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk);
     return launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, hflag[1] != 0);

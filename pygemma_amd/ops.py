@@ -126,7 +126,7 @@ def rotate_geno(U, X, ctx=None, ldx=None):
         out = dXr.download((p, ldx), np.float32) if ok.value else None
         for b in (dU, dX, dprep, dwork, dXr):
             b.free()
-        return out, bool(ok.value)
+        return out, int(ok.value)     # 1: genotype-valued block, 2: general finite block (X split in two fp16 planes)
     finally:
         if own:
             ctx.close()

@@ -61,17 +61,29 @@ def test_rotate_genotype_fast_path(n, p, std, ctx):
     assert (got[:, n:] == 0).all()
 
 
-def test_rotate_genotype_rejects_non_genotype_block(ctx):
+def test_rotate_non_genotype_block_split_path_and_nan_rejection(ctx):
+    """A finite block that is not genotype-valued (imputed dosages) goes through the same fp16 GEMM with X split in two
+    fp16 planes (is_geno = 2), within the fp32-GEMM error class; a block with a NaN is left to the fp32 kernel."""
     from pygemma_amd import ops
     rng = np.random.default_rng(3)
-    n, p = 128, 64
+    n, p = 500, 300
     U = np.linalg.qr(rng.standard_normal((n, n)))[0].astype(np.float32)
     X = _geno(rng, n, p, True)
-    X[5, 7] += 0.125; X[9, 7] -= 0.0625     # a fourth AND a fifth value in one column (imputed dosages)
+    X[5, 7] += 0.125; X[9, 7] -= 0.0625     # a fourth AND a fifth value in one column
+    X[:, 11] = rng.uniform(0, 2, n)          # a dosage column
+    X[:, 12] = rng.standard_normal(n) * 1e-20; X[:, 13] = rng.standard_normal(n) * 1e20   # extreme scales
     got, ok = ops.rotate_geno(U, X, ctx=ctx)
-    assert not ok and got is None
+    assert ok == 2
+    exact = (U.astype(np.float64).T @ X.astype(np.float64)).T
+    f32p = ops.rotate(U, X, ctx=ctx)[:, :n]
+    bound = (np.abs(X.astype(np.float64)).T @ np.abs(U.astype(np.float64)))
+    err_g = np.abs(got[:, :n] - exact) / bound
+    err_f = np.abs(f32p - exact) / bound
+    assert err_g.max() <= 4 * 2.0 ** -24 * np.sqrt(n) and np.median(err_g) <= 2 * max(np.median(err_f), 1e-9)
+    assert (got[:, n:] == 0).all()
     X = _geno(rng, n, p, True); X[3, 3] = np.nan
-    assert ops.rotate_geno(U, X, ctx=ctx)[1] is False
+    got, ok = ops.rotate_geno(U, X, ctx=ctx)
+    assert ok == 0 and got is None
 
 
 @pytest.mark.parametrize("n,p,std", [(300, 200, False), (1000, 513, True)])
