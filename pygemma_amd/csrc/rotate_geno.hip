@@ -525,11 +525,8 @@ static int launch_geno_gemm(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep
     gp.scale = (const float *)(sums + (size_t)(kt + 1) * n);
     gp.v0 = v0; gp.dx = dx; gp.Xr = Xr;
     constexpr int WLDS = 5 * 256 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rotate_geno_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
-        attr_set = true;
-    }
+    // per device (the attribute belongs to the function object of the current device; contexts of several GPUs share this process)
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rotate_geno_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
     gp.tiles_m = (int)((p + 255) / 256); gp.tiles_n = (int)((n + 255) / 256); gp.KT = (int)kt;
     const long long T = (long long)gp.tiles_m * gp.tiles_n;
     PG_REQUIRE(T < (1LL << 31), "genotype rotation: too many tiles");
