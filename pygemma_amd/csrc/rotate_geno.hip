@@ -1,31 +1,25 @@
-// rotate_geno.hip — H2 fast path for GENOTYPE columns: X <- U'X when every column of the SNP block
-// takes at most three equally spaced values (hard-called genotypes 0/1/2, raw or centred/standardised — what
-// lmm.pygemma is fed by every caller in the reference: experiments/*/run_*.py, tests/test_pygemma.py:184-192).
+// rotate_geno.hip — H2 on the fp16 MFMA pipe: X <- U'X for a block of SNP columns, 16x the fp32-MFMA rate.
 //
-//   x_g = v0_g + dx_g * code_g,  code in {0,1,2}   =>   U'x_g = v0_g * (U'1) + dx_g * (U' code_g)
+// U is split once into two fp16 planes, S*U = H1 + H2 + e, S the power of two that puts S*max|U| in [2^14, 2^15) (keeps H2
+// out of the fp16 subnormals), round-to-nearest at both steps: |e| <= 2^-24 |S*U| — the size of float32's own rounding of U
+// (measured: the split adds 0.6x the error U already carries from that rounding, 1/20 of the fp32 accumulation error).
 //
-// Blocks that are NOT genotype-valued (imputed dosages, any finite float X) take the same GEMM with X itself split in two
-// fp16 planes, s_g x = X1 + X2 + e (s_g a per-column power of two, |e| <= 2^-24 |s_g x|): pass 1 on X1 with both U planes,
-// pass 2 accumulates X2 (its H2 part is below 2^-24 and costs nothing to keep).  Only blocks with a NaN/Inf are left to
-// the fp32-MFMA kernel (pg_rotate_dev), whose NaN/Inf propagation is the reference's.
+// (1) GENOTYPE columns — at most three equally spaced values (hard calls 0/1/2, raw or centred/standardised: what every
+//     caller in the reference feeds lmm.pygemma, experiments/*/run_*.py, tests/test_pygemma.py:184-192):
+//         x_g = v0_g + dx_g * code_g,  code in {0,1,2}   =>   U'x_g = v0_g * (U'1) + dx_g * (U' code_g)
+//     The codes are exact in fp16, every product code*H is exact in fp32, and the two partial GEMMs accumulate into ONE fp32
+//     accumulator (K' = 2K).  U'1 in fp64, combine in fp64, one rounding to fp32.
+// (2) a genotype column may hold ONE other value o_g anywhere (missing calls imputed with the column mean, as the reference's
+//     callers do: experiments/benchmarks/benchmarks.py:243-244):  x_g = v0_g + dx_g * code_g + (o_g - v0_g) * ind_g  (code 0
+//     where ind = 1); the block takes a second, accumulating pass of the same GEMM on the 0/1 indicator plane.
+// (3) any other FINITE block (imputed dosages, arbitrary float X): X itself in two fp16 planes, s_g x = X1 + X2 + e (s_g a
+//     per-column power of two, |e| <= 2^-24 |s_g x|): pass 1 on X1, pass 2 accumulates X2.
+// (4) a block with a NaN/Inf is left to the fp32-MFMA kernel (pg_rotate_dev), whose propagation is the reference's sgemm's.
+// Error class of (1)-(3) = fp32 accumulation, the same as the fp32-MFMA kernel and the reference's sgemm (lmm/lmm.py:244).
 //
-// A genotype column may in addition hold ONE other value o_g anywhere (missing calls imputed with the column mean — what the
-// reference's callers do before lmm.pygemma, experiments/benchmarks/benchmarks.py:243-244):
-//   x_g = v0_g + dx_g * code_g + (o_g - v0_g) * ind_g   (code 0 where ind = 1)
-// and the block takes a second pass of the same GEMM on the 0/1 indicator plane, accumulated onto the first.
-//
-// The codes are exact in fp16, so U' code needs only U split into two fp16 planes, S*U = H1 + H2 + e with S the power of two that puts S*max|U| in [2^14, 2^15)
-// (keeps H2 out of the fp16 subnormals) and round-to-nearest at both steps: |e| <= 2^-24 |S*U| — the size of fp32's own
-// quantisation of U (measured: the split adds 0.6x the error U already carries from its rounding to fp32, and 1/20 of
-// the fp32 accumulation error).  Every product code*H is exact in fp32 and the two partial GEMMs accumulate into ONE fp32
-// accumulator on the fp16 MFMA pipe (v_mfma_f32_16x16x32_f16, 16x the fp32-MFMA rate; 2 passes => 8x fewer matrix
-// cycles than the fp32 path).  Error class = fp32 accumulation, the same as the fp32-MFMA kernel and as the reference's
-// sgemm (lmm/lmm.py:244).  U'1 is taken in fp64.
-//
-// Layout: both operands K-contiguous ("NT" GEMM): Gt [p][ldk] fp16 codes (SNP-major), Up [n][2*KT*GBK] fp16 with the
-// two planes of each 64-sample K-tile interleaved, so the kernel is a plain GEMM over K' = 2K whose A tile index is
-// kt'/2.  256 x 256 tile per 512-thread workgroup (v_mfma_f32_16x16x32_f16: the 16x16x32 shape sustains a higher clock than
-// 32x32x16 at equal cycles per flop), BK = 64, operands staged by LDS-DMA into XOR-swizzled LDS rings (see rotate_geno_kernel).
+// Layout: both operands K-contiguous ("NT" GEMM): Gt [p][ldk] fp16 (SNP-major), Up [n][2*KT*64] fp16 with the two planes of
+// each 64-sample K-tile interleaved, so the kernel is a plain GEMM over K' = 2K whose A tile index is kt'/2.  Kernel design:
+// see rotate_geno_kernel.
 #include "common.hpp"
 
 namespace pg {
@@ -33,11 +27,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
 
-#ifndef PG_GBK
-#define PG_GBK 64
-#endif
-constexpr int GBM = 256, GBN = 256, GBK = PG_GBK;
-static_assert(GBK == 64, "the LDS image is 128-byte rows: 64 fp16 per K-tile");
+constexpr int GBK = 64;   // samples per K-tile: the LDS image is 128-byte rows = 64 fp16
 
 __device__ __forceinline__ unsigned short f32_to_f16_rn(float f)
 {
