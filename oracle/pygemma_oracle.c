@@ -163,7 +163,7 @@ void orc_hinv(float lam, const float *d, long n, double *out)
  * f32(f32(lam*d)+1), f32 pairwise sum. */
 float orc_logdet_H(float lam, const float *d, long n)
 {
-    float *t = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    float *t = (float *)calloc((size_t)(n > 0 ? n : 1), sizeof(float));
     for (long i = 0; i < n; i++) {
         volatile float a = lam * d[i];
         volatile float b = a + 1.0f;
