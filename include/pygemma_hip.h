@@ -86,6 +86,12 @@ int pg_assoc(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const flo
              const float *X_n_by_p, int grid, float *beta, float *se, float *tau, float *lambda, double *F,
              double *pval, unsigned long long *stats2);
 
+/* pg_assoc over several GPUs of the node: contiguous blocks of ceil(p/ngpu) SNP columns like the reference's
+ * SampleIter (lmm/lmm.py:427-434) — one host thread and one context per GPU, outputs in SNP order.  No collective is
+ * needed: SNPs are independent and every GPU copies its block of results into its slice of the host arrays. */
+int pg_assoc_multi(int ngpu, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
+                   const float *X_n_by_p, int grid, float *beta, float *se, float *tau, float *lambda, double *F, double *pval);
+
 /* scipy.stats.f.sf(F, 1, dfd) (lmm/lmm.py:482) for a device vector */
 int pg_fdist_sf_dev(pg_ctx *ctx, int64_t count, const double *F, double dfd, double *pval);
 

@@ -2,6 +2,11 @@
 // (include/pygemma_hip.h).  No exceptions cross the ABI; errors go to a thread-local string.
 #include "common.hpp"
 
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <vector>
+
 #include <cmath>
 #include <functional>
 #include <new>
@@ -248,13 +253,12 @@ extern "C" int pg_event_elapsed_ms(pg_ctx *ctx, void *start, void *stop, float *
     return PG_OK;
 }
 
-// host-pointer convenience around pg_assoc_dev: X in the reference layout (n x p), copied in SNP batches
-extern "C" int pg_assoc(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
-                        const float *X, int grid, float *beta, float *se, float *tau, float *lambda, double *F,
-                        double *pval, unsigned long long *stats2)
+// host-pointer convenience around pg_assoc_dev: columns [0, p) of a host matrix X in the reference layout (n rows, row
+// stride ldX floats); the outputs are host arrays of length p
+static int assoc_host_block(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
+                            const float *X, int64_t ldX, int grid, float *beta, float *se, float *tau, float *lambda, double *F,
+                            double *pval, unsigned long long *stats2)
 {
-    PG_REQUIRE(ctx && d && Wr && yr && X && beta && se && tau && lambda && F, "pg_assoc: NULL argument");
-    PG_REQUIRE(n >= 2 && p >= 0 && c >= 0, "pg_assoc: bad shape");
     if (p == 0) return PG_OK;
     PG_HIP(hipSetDevice(ctx->device));
     const int64_t ldx = (n + 63) / 64 * 64;
@@ -280,7 +284,7 @@ extern "C" int pg_assoc(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d
     PG_TRY(hipMemcpyAsync(dd, d, n * 4, hipMemcpyHostToDevice, ctx->stream));
     PG_TRY(hipMemcpyAsync(dW, Wr, (size_t)n * c * 4, hipMemcpyHostToDevice, ctx->stream));
     PG_TRY(hipMemcpyAsync(dy, yr, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    PG_TRY(hipMemcpyAsync(dX, X, (size_t)n * p * 4, hipMemcpyHostToDevice, ctx->stream));
+    PG_TRY(hipMemcpy2DAsync(dX, (size_t)p * 4, X, (size_t)ldX * 4, (size_t)p * 4, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     rc = pg_transpose_dev(ctx, n, p, dX, p, dXr, ldx);
     if (!rc) rc = pg_assoc_dev(ctx, n, c, p, dd, dW, dy, dXr, ldx, grid, dout, dout + p, dout + 2 * p, dout + 3 * p, dF,
                                pval ? dF + p : nullptr, dstats);
@@ -295,5 +299,50 @@ extern "C" int pg_assoc(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d
     PG_TRY(hipStreamSynchronize(ctx->stream));
 #undef PG_TRY
     cleanup();
+    return PG_OK;
+}
+
+extern "C" int pg_assoc(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
+                        const float *X, int grid, float *beta, float *se, float *tau, float *lambda, double *F,
+                        double *pval, unsigned long long *stats2)
+{
+    PG_REQUIRE(ctx && d && Wr && yr && X && beta && se && tau && lambda && F, "pg_assoc: NULL argument");
+    PG_REQUIRE(n >= 2 && p >= 0 && c >= 0, "pg_assoc: bad shape");
+    return assoc_host_block(ctx, n, c, p, d, Wr, yr, X, p, grid, beta, se, tau, lambda, F, pval, stats2);
+}
+
+// The same over several GPUs of this node: contiguous SNP blocks of ceil(p/ngpu) columns like the reference's
+// SampleIter (lmm/lmm.py:427-434), one host thread + one context per GPU, results written in SNP order.  SNPs are
+// independent, so there is no device-to-device exchange: the gather is each GPU's copy-out into its slice of the outputs.
+extern "C" int pg_assoc_multi(int ngpu, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
+                              const float *X, int grid, float *beta, float *se, float *tau, float *lambda, double *F, double *pval)
+{
+    PG_REQUIRE(d && Wr && yr && X && beta && se && tau && lambda && F, "pg_assoc_multi: NULL argument");
+    PG_REQUIRE(n >= 2 && p >= 0 && c >= 0 && ngpu >= 1, "pg_assoc_multi: bad arguments");
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have < 1) { set_error("pg_assoc_multi: no GPU visible"); return PG_ENODEV; }
+    const int G = (int)std::min<int64_t>(std::min(ngpu, have), std::max<int64_t>(p, 1));
+    const int64_t cols = (p + G - 1) / G;
+    std::vector<int> rcs(G, PG_OK);
+    std::vector<std::string> msgs(G);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; g++) {
+        th.emplace_back([&, g]() {
+            const int64_t a = g * cols, b = std::min<int64_t>(p, a + cols);
+            if (a >= b) return;
+            pg_ctx *ctx = nullptr;
+            int rc = pg_ctx_create(g, &ctx);
+            if (!rc) {
+                rc = assoc_host_block(ctx, n, c, b - a, d, Wr, yr, X + a, p, grid, beta + a, se + a, tau + a, lambda + a, F + a,
+                                      pval ? pval + a : nullptr, nullptr);
+                if (rc) msgs[g] = pg_last_error();      // thread-local text: carry it to the caller's thread
+                pg_ctx_destroy(ctx);
+            } else msgs[g] = pg_last_error();
+            rcs[g] = rc;
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int g = 0; g < G; g++)
+        if (rcs[g]) { set_error("pg_assoc_multi: GPU %d: %s", g, msgs[g].c_str()); return rcs[g]; }
     return PG_OK;
 }

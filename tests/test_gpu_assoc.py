@@ -68,3 +68,23 @@ def test_fdist_sf_device_vs_scipy_fixture(ctx):
         ok = ref > 1e-300
         np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-8)
         assert (got[~ok] <= 1e-299).all()
+
+
+def test_pg_assoc_multi_matches_single_context():
+    """pg_assoc_multi (SampleIter-style SNP blocks over the visible GPUs, host pointers) == pg_assoc, bit for bit, for any
+    requested GPU count (more than visible: clamped; more than SNPs: clamped)."""
+    import ctypes as C
+    from pygemma_amd import _lib, ops, synth
+    rp = synth.rotated_panel(160, 301, 3, seed=9)
+    d, X, Y, W = rp["d"], np.ascontiguousarray(rp["X"]), rp["Y"].reshape(-1), rp["W"]
+    ref = ops.assoc(d, W, Y, X)
+    L = _lib.load()
+    n, p = X.shape
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for ngpu in (1, 2, 8):
+        beta, se, tau, lam = (np.empty(p, np.float32) for _ in range(4))
+        F, pv = np.empty(p, np.float64), np.empty(p, np.float64)
+        _lib.check(L.pg_assoc_multi(ngpu, n, W.shape[1], p, vp(d), vp(np.ascontiguousarray(W)), vp(np.ascontiguousarray(Y)), vp(X), 0,
+                                    vp(beta), vp(se), vp(tau), vp(lam), vp(F), vp(pv)), "pg_assoc_multi")
+        assert (beta.view(np.uint32) == ref["beta"].view(np.uint32)).all() and (se == ref["se_beta"]).all()
+        assert (lam.astype(np.float64) == ref["lambda"]).all() and (F == ref["F_wald"]).all() and (pv == ref["p_wald"]).all()
