@@ -37,6 +37,9 @@ constexpr int WPB = 4;    // wavefronts (= SNPs) per workgroup
 #ifndef PG_PFD
 #define PG_PFD 2            // prefetch ring depth
 #endif
+#ifndef PG_SCAN_NV
+#define PG_SCAN_NV 96        // decade-scan accumulators per pass (x-entries of as many lambdas as fit)
+#endif
 #ifndef PG_WAVES
 #define PG_WAVES 2          // waves per SIMD the register allocation is held to
 #endif
@@ -199,8 +202,11 @@ template <int C> struct Shape {
     static constexpr int NP = M * (M + 1) / 2;  // lower-triangle entries
     static constexpr int SLOTS = (NP + 63) / 64;               // Gram entries owned per lane
     static constexpr int NV0 = NP < 64 ? NP : 64, NV1 = NP > 64 ? NP - 64 : 0;
-    // scan: decade lambdas handled per pass (their 2M x-entries each must fit one 64-value reduce-scatter)
-    static constexpr int G = (64 / (2 * M)) < 1 ? 1 : ((64 / (2 * M)) > 4 ? 4 : (64 / (2 * M)));
+    // scan: decade lambdas handled per pass
+    // (two reduce-scatters of <= 64 and <= 32 values; PG_SCAN_NV caps the per-pass accumulators: 2 VGPRs each
+    // — measured: 96 is best for c >= 3, 64 for c <= 2 where one more lambda per pass starts to spill)
+    static constexpr int SCAN_NV = (M <= 4 && PG_SCAN_NV > 64) ? 64 : PG_SCAN_NV;
+    static constexpr int G = (SCAN_NV / (2 * M)) < 1 ? 1 : ((SCAN_NV / (2 * M)) > 11 ? 11 : (SCAN_NV / (2 * M)));
     // powers accumulated per pass over n: fused while the accumulators fit the register budget of 2 waves/SIMD
     static constexpr bool FUSE_PQ = NP <= PG_FUSE_PQ_MAX, FUSE_PQR = NP <= PG_FUSE_PQR_MAX;
 };
@@ -506,11 +512,13 @@ __global__ __launch_bounds__(64) void setup_tabs_kernel(AssocParams pr)
 template <int C, int GG>
 __device__ __forceinline__ void scan_accumulate(const AssocParams &pr, const float *xrow, int t0, int lane, double *xent)
 {
-    constexpr int M = Shape<C>::M, NV = GG * 2 * M, NVP = next_pow2(NV);
-    static_assert(NV <= 64, "scan group too large");
-    double acc[NVP];
+    constexpr int M = Shape<C>::M, NV = GG * 2 * M;
+    constexpr int NV0 = NV < 64 ? NV : 64, NV1 = NV > 64 ? NV - 64 : 0;      // values reduced by the first / second reduce-scatter
+    constexpr int NVP0 = next_pow2(NV0), NVP1 = next_pow2(NV1 > 0 ? NV1 : 1);
+    static_assert(NV <= 128, "scan group too large");
+    double acc[NV0 == 64 ? 64 + NVP1 : NVP0];
 #pragma unroll
-    for (int k = 0; k < NVP; k++) acc[k] = 0.0;
+    for (int k = 0; k < (NV0 == 64 ? 64 + NVP1 : NVP0); k++) acc[k] = 0.0;
     struct SE { Elem<C> e; float h[GG]; };
     pipelined<SE>(pr.niter, [&](SE &q, int it) {
         const int i = it * 64 + lane;
@@ -541,9 +549,22 @@ __device__ __forceinline__ void scan_accumulate(const AssocParams &pr, const flo
             }
         }
     });
-    const double tot = reduce_scatter<NVP>(acc, lane);
-    const int idx = lane % NVP;
-    if (idx < NV && lane < NVP) xent[t0 * 2 * M + idx] = tot;
+    {
+        double t[NVP0];
+#pragma unroll
+        for (int k = 0; k < NVP0; k++) t[k] = acc[k];
+        const double tot = reduce_scatter<NVP0>(t, lane);
+        const int idx = lane % NVP0;
+        if (idx < NV0 && lane < NVP0) xent[t0 * 2 * M + idx] = tot;
+    }
+    if constexpr (NV1 > 0) {
+        double t[NVP1];
+#pragma unroll
+        for (int k = 0; k < NVP1; k++) t[k] = acc[64 + k];
+        const double tot = reduce_scatter<NVP1>(t, lane);
+        const int idx = lane % NVP1;
+        if (idx < NV1 && lane < NVP1) xent[t0 * 2 * M + 64 + idx] = tot;
+    }
 }
 template <int C, int T0>
 __device__ __forceinline__ void scan_all(const AssocParams &pr, const float *xrow, int lane, double *xent)
