@@ -227,6 +227,7 @@ def main():
 
     if rank != 0:
         if world > 1:
+            dist.barrier()                   # rank 0 finishes its report, then everybody tears the group down together
             dist.destroy_process_group()
         return
 
@@ -320,6 +321,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "SNPs/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
     print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
