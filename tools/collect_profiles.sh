@@ -27,5 +27,7 @@ pass sq_assoc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GR
 pass fetch_rot FETCH_SIZE -- $ROOT/tools/bench_rotate.py 10000 16384
 pass write_rot WRITE_SIZE -- $ROOT/tools/bench_rotate.py 10000 16384
 pass sq_rot SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $ROOT/tools/bench_rotate.py 10000 16384
+pass sq_dgemm_panel SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $ROOT/tools/bench_dgemm.py 8192 8192 128 1
+pass sq_dgemm_big SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $ROOT/tools/bench_dgemm.py 8192 8192 8192
 find $OUT -name "*.db" -delete
 ls -R $OUT | head -60

@@ -69,6 +69,15 @@ for key, kern, suffix, algo in (("rotate_geno_kernel", "rotate_geno_kernel", "ge
     except Exception as ex:
         e["error"] = repr(ex)
     pm[key] = e
+for key, name, flops in (("dgemm_panel_update", "sq_dgemm_panel", 2.0 * 8192 * 8192 * 128), ("dgemm_8192_cubed", "sq_dgemm_big", 2.0 * 8192 ** 3)):
+    try:
+        sq, dur = pmc(name)
+        gui, ms, mf = avg(sq, "dgemm_kernel", "GRBM_GUI_ACTIVE"), avg(dur, "dgemm_kernel"), avg(sq, "dgemm_kernel", "SQ_VALU_MFMA_BUSY_CYCLES")
+        pm[key] = {"note": "fp64 MFMA GEMM of the eigensolver (v_mfma_f64_16x16x4_f64), tools/bench_dgemm.py", "avg_ms_profiled": ms,
+                   "TFLOPs": flops / ms / 1e9, "frac_of_78.6": flops / ms / 1e9 / 78.6, "clock_GHz": gui / 8 / (ms * 1e6),
+                   "mfma_busy_frac": mf / (1024 * gui / 8)}
+    except Exception as ex:
+        pm[key] = {"error": repr(ex)}
 pm["rotate_geno_kernel"]["note"] = "GEMM kernel only (fp16 codes 2 B/elem in, 2 fp16 planes of U, f32 out); the detect/encode passes read the raw f32 block twice more"
 summ["pmc"] = pm
 json.dump(summ, open(os.path.join(P, f"{tag}_summary.json"), "w"), indent=1)
