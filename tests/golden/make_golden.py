@@ -182,6 +182,34 @@ def gen_eigen_true():
     print("eigen_true_n300.npz")
 
 
+def gen_eigen_true_imputed():
+    """Tier C fixtures for the two other input classes of the rotation: raw 0/1/2 calls with missing entries imputed by the
+    column mean (what the reference's callers feed, experiments/benchmarks/benchmarks.py:233-244) and continuous dosages
+    (experiments/wtccc/run_pygemma_imputed.py).  K is regenerated by the test from the seed (its checksum is stored)."""
+    n, p, c, seed = 600, 150, 5, 777
+    rng = np.random.default_rng(seed)
+    GK = synth.genotypes(rng, n, 2 * n)
+    K = (GK @ GK.T / (2 * n)).astype(np.float32)
+    G = rng.binomial(2, rng.uniform(0.05, 0.5, p), size=(n, p)).astype(np.float64)
+    miss = rng.random((n, p)) < 0.02
+    miss[:, ::11] = False
+    Gm = np.where(miss, np.nan, G)
+    mu = np.nanmean(Gm, axis=0)
+    X_imp = np.where(miss, mu[None, :], G).astype(np.float32)
+    X_dos = np.clip(G + rng.normal(0, 0.15, G.shape), 0, 2).astype(np.float32)
+    W = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, c - 1))], axis=1).astype(np.float32)
+    y = (0.25 * G[:, 0] + GK @ (rng.standard_normal(2 * n) * np.sqrt(0.5 / (2 * n))) + rng.standard_normal(n) * np.sqrt(0.5))
+    y = y.astype(np.float32).reshape(-1, 1)
+    out = {"versions": VERS, "seed": np.int64(seed), "K_sum": np.float64(K.astype(np.float64).sum()), "X_imp": X_imp, "X_dos": X_dos,
+           "W": W, "Y": y}
+    for tag, X in (("imp", X_imp), ("dos", X_dos)):
+        df = quiet(ref.pygemma, y, X, W, K, grid=False, eigen=True, nproc=1)
+        for col in ["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"]:
+            out[f"{tag}_{col}"] = df[col].to_numpy()
+    np.savez_compressed(os.path.join(HERE, "eigen_true_imputed_n600.npz"), **out)
+    print("eigen_true_imputed_n600.npz")
+
+
 def gen_mouse():
     """config #1 shape: real phenotype column of data/mouse_hs1940.pheno.txt (NA -> mean, as
     experiments/animal_gwas/run_gwas.py:83), SYNTHETIC genotypes / K (the real ones are not bundled,
@@ -206,6 +234,8 @@ def gen_mouse():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["precompute", "panels", "brentq", "fdist", "nplog", "eigen", "mouse"]
+    if "imputed" in which:
+        gen_eigen_true_imputed()
     if "precompute" in which:
         gen_precompute()
     if "panels" in which:

@@ -160,3 +160,33 @@ def test_pygemma_int8_genotypes_match_float_input(dtype):
     b = lmm.pygemma(y, G2.astype(np.float32), W, K)
     for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
         assert (a[col].to_numpy() == b[col].to_numpy()).all(), col
+
+
+@pytest.mark.parametrize("tag", ["imp", "dos"])
+def test_pygemma_tier_c_imputed_and_dosage_inputs(tag):
+    """Tier C on the two other input classes of the fp16 rotation, against runs of the real reference: raw 0/1/2 calls with
+    mean-imputed missing entries (genotype path + indicator pass) and continuous dosages (X split into two fp16 planes).
+    Same bar as above: not further from an fp64 truth pipeline than the reference's own float32 pipeline is."""
+    from oracle import oracle as O
+    from pygemma import lmm
+    from pygemma_amd import synth
+    z = np.load(os.path.join(G, "eigen_true_imputed_n600.npz"))
+    X, W, Y = z["X_" + tag], z["W"], z["Y"]
+    n, p = X.shape
+    rng = np.random.default_rng(int(z["seed"]))
+    GK = synth.genotypes(rng, n, 2 * n)
+    K = (GK @ GK.T / (2 * n)).astype(np.float32)
+    assert float(K.astype(np.float64).sum()) == float(z["K_sum"])          # the generator's K, regenerated
+    df = lmm.pygemma(Y, X, W, K, eigen=True, nproc=1)
+    K64 = np.tril(K.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
+    d, U = np.linalg.eigh(K64)
+    rot = lambda A: (U.T @ A.astype(np.float64)).astype(np.float32)
+    truth = O.calculate(np.maximum(d, 0).astype(np.float32), rot(Y), rot(W), rot(X), grid=False, order=0, nthreads=4)
+    for col in ["beta", "se_beta", "p_wald"]:
+        t = truth[col].astype(np.float64)
+        eb = np.abs(df[col].to_numpy().astype(np.float64) - t) / np.abs(t)
+        er = np.abs(z[f"{tag}_{col}"].astype(np.float64) - t) / np.abs(t)
+        assert np.median(eb) <= max(1.5 * np.median(er), 5e-7), (col, np.median(eb), np.median(er))
+        assert np.quantile(eb, 0.99) <= max(2.0 * np.quantile(er, 0.99), 5e-6), (col, eb.max(), er.max())
+    relp = np.abs(df["p_wald"].to_numpy() - z[f"{tag}_p_wald"]) / z[f"{tag}_p_wald"]
+    assert (relp <= 1e-3).mean() >= 0.99
