@@ -14,9 +14,16 @@
 #include "common.hpp"
 #include "dgemm.hpp"
 
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <thread>
+#include <vector>
 
 namespace pg {
 
@@ -464,7 +471,7 @@ __device__ __forceinline__ double wave_sum(double v)
     for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
     return v;
 }
-__global__ __launch_bounds__(256) void secular_kernel(int k, const double *dl, const double *w, double rho, double *Dm, double *lam_out)
+__global__ __launch_bounds__(256) void secular_kernel(int k, const double *dl, const double *w, double rho, const int *rp, double *Dm, double *lam_out)
 {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -533,17 +540,17 @@ __global__ __launch_bounds__(256) void secular_kernel(int k, const double *dl, c
         if (tnew == tau) break;
         tau = tnew;
     }
-    for (int i = lane; i < k; i += 64) Dm[(size_t)i * k + j] = (dl[i] - dorg) - tau;
+    for (int i = lane; i < k; i += 64) Dm[(size_t)rp[i] * k + j] = (dl[i] - dorg) - tau;   // row of pole i: its slot in the type-grouped order
     if (lane == 0) lam_out[j] = dorg + tau;
 }
 
 // zhat_i = sign(w_i) sqrt| Dm[i][i] * prod_{j != i} Dm[i][j] / (dl_i - dl_j) |   (one wavefront per i)
-__global__ __launch_bounds__(256) void zhat_kernel(int k, const double *dl, const double *w, const double *Dm, double *zh)
+__global__ __launch_bounds__(256) void zhat_kernel(int k, const double *dl, const double *w, const int *rp, const double *Dm, double *zh)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave;
     if (i >= k) return;
-    const double *row = Dm + (size_t)i * k;
+    const double *row = Dm + (size_t)rp[i] * k;
     const double di = dl[i];
     double prod = 1.0;
     for (int j = lane; j < k; j += 64) prod *= (j == i) ? row[j] : row[j] / (di - dl[j]);
@@ -553,19 +560,19 @@ __global__ __launch_bounds__(256) void zhat_kernel(int k, const double *dl, cons
 
 // U[:, j] = (zh_i / Dm[i][j])_i, normalised; in place over Dm.  64 columns per workgroup (coalesced across j), the rows
 // split over the 4 waves, column norms combined through LDS in a fixed order.
-__global__ __launch_bounds__(256) void uvec_kernel(int k, const double *zh, double *Dm)
+__global__ __launch_bounds__(256) void uvec_kernel(int k, const double *zh, const int *rp, double *Dm)
 {
     __shared__ double part[4][64];
     const int jj = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + jj;
     double ss = 0.0;
     if (j < k)
-        for (int i = rg; i < k; i += 4) { const double v = zh[i] / Dm[(size_t)i * k + j]; ss += v * v; }
+        for (int i = rg; i < k; i += 4) { const double v = zh[i] / Dm[(size_t)rp[i] * k + j]; ss += v * v; }
     part[rg][jj] = ss;
     __syncthreads();
     if (j >= k) return;
     const double inv = 1.0 / sqrt(((part[0][jj] + part[1][jj]) + part[2][jj]) + part[3][jj]);
-    for (int i = rg; i < k; i += 4) { const double v = zh[i] / Dm[(size_t)i * k + j]; Dm[(size_t)i * k + j] = v * inv; }
+    for (int i = rg; i < k; i += 4) { const size_t at = (size_t)rp[i] * k + j; const double v = zh[i] / Dm[at]; Dm[at] = v * inv; }
 }
 
 __global__ void copy_block_kernel(int n, int r0, int nm, const double *Qin, double *Qout)
@@ -589,6 +596,8 @@ struct MergePlan {
     double rho;
     std::vector<double> dl, w, ddefl;   // non-deflated poles/weights; values of the deflated columns
     std::vector<int> col;               // global source column for each output slot (k non-deflated, then deflated)
+    std::vector<int> rowpos;            // slot (0..k-1) of sorted pole i: non-deflated columns are stored grouped by type
+    int k1 = 0, k2 = 0;                 // columns living in the upper block only / in both (Givens-mixed); the rest: lower only
     std::vector<Rot> rots;
 };
 
@@ -607,8 +616,12 @@ static void plan_merge(MergePlan &mp, const double *d_in, const double *z_in, do
     double dmax = 0.0, zmax = 0.0;
     for (int i = 0; i < nm; i++) { dmax = std::max(dmax, fabs(d[i])); zmax = std::max(zmax, fabs(z[i])); }
     const double tol = 8.0 * eps * std::max(dmax, zmax);
-    mp.k = 0; mp.dl.clear(); mp.w.clear(); mp.ddefl.clear(); mp.col.clear(); mp.rots.clear();
+    mp.k = 0; mp.dl.clear(); mp.w.clear(); mp.ddefl.clear(); mp.col.clear(); mp.rots.clear(); mp.rowpos.clear(); mp.k1 = mp.k2 = 0;
     std::vector<int> defl_cols;
+    // column types as in dlaed2: 1 = non-zero in the upper block only, 3 = lower only, 2 = both (after a Givens rotation of
+    // columns from the two blocks): the update GEMM then only multiplies the non-zero parts (half the flops of a dense product)
+    std::vector<int> typ(nm);
+    for (int i = 0; i < nm; i++) typ[i] = (i < mp.n1) ? 1 : 3;
     if (mp.rho * zmax <= tol) {
         for (int jj = 0; jj < nm; jj++) { defl_cols.push_back(idx[jj]); mp.ddefl.push_back(d[idx[jj]]); }
     } else {
@@ -623,6 +636,7 @@ static void plan_merge(MergePlan &mp, const double *d_in, const double *z_in, do
             c_ /= tau; s_ = -s_ / tau;
             if (fabs(t * c_ * s_) <= tol) {
                 z[nj] = tau; z[pj] = 0.0;
+                if (typ[pj] != typ[nj]) typ[nj] = 2;
                 mp.rots.push_back({mp.s + pj, mp.s + nj, c_, s_});
                 const double tt = d[pj] * c_ * c_ + d[nj] * s_ * s_;
                 d[nj] = d[pj] * s_ * s_ + d[nj] * c_ * c_;
@@ -633,7 +647,12 @@ static void plan_merge(MergePlan &mp, const double *d_in, const double *z_in, do
         }
         if (pj >= 0) nd.push_back(pj);
         mp.k = (int)nd.size();
-        for (int q : nd) { mp.dl.push_back(d[q]); mp.w.push_back(z[q]); mp.col.push_back(mp.s + q); }
+        for (int q : nd) { mp.dl.push_back(d[q]); mp.w.push_back(z[q]); }
+        mp.rowpos.assign(mp.k, 0);
+        int slot = 0;
+        for (int t = 1; t <= 3; t++)
+            for (int i = 0; i < mp.k; i++)
+                if (typ[nd[i]] == t) { mp.rowpos[i] = slot++; mp.col.push_back(mp.s + nd[i]); if (t == 1) mp.k1++; else if (t == 2) mp.k2++; }
     }
     for (int q : defl_cols) mp.col.push_back(mp.s + q);
 }
@@ -649,6 +668,16 @@ struct StedcWork {
 static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_in, std::vector<double> &evals, StedcWork &wk, double **Zout)
 {
     hipStream_t st = ctx->stream;
+    const bool timing = getenv("PG_SYEVD_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto mark = [&](const char *what, int a, int b) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        const double t = now();
+        fprintf(stderr, "[stedc n=%d] %-10s %6d %6d %8.2f ms\n", n, what, a, b, (t - t_prev) * 1e3);
+        t_prev = t;
+    };
     std::vector<double> d(d_in, d_in + n), e(e_in, e_in + (n > 1 ? n - 1 : 0));
     // ---- leaves
     const int nleaf = (n + DC_LEAF - 1) / DC_LEAF;
@@ -660,14 +689,25 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
     std::vector<double> S((size_t)n * maxleaf, 0.0);
     std::vector<int> itab(3 * (size_t)n + 16, 0);
     int *leaf_start = itab.data(), *leaf_size = itab.data() + n, *leaf_of_row = itab.data() + 2 * n;
-    for (int l = 0; l < nleaf; l++) {
-        const int s = bs[l], m = bs[l + 1] - bs[l];
-        std::vector<double> dd(d.begin() + s, d.begin() + s + m), ee(m, 0.0), Zl((size_t)m * m);
-        for (int i = 0; i + 1 < m; i++) ee[i] = e[s + i];
-        if (host_tql2(m, dd.data(), ee.data(), Zl.data(), m) != 0) { set_error("stedc: leaf QL did not converge"); return PG_EINVAL; }
-        for (int i = 0; i < m; i++) { d[s + i] = dd[i]; for (int j = 0; j < m; j++) S[(size_t)(s + i) * maxleaf + j] = Zl[(size_t)i * m + j]; }
-        leaf_start[l] = s; leaf_size[l] = m;
-        for (int i = 0; i < m; i++) leaf_of_row[s + i] = l;
+    {   // the leaves are independent small dense problems: a few host threads share them (disjoint slices of d, S and itab)
+        std::atomic<int> next(0), failed(0);
+        auto work = [&]() {
+            for (int l = next.fetch_add(1); l < nleaf; l = next.fetch_add(1)) {
+                const int s = bs[l], m = bs[l + 1] - bs[l];
+                std::vector<double> dd(d.begin() + s, d.begin() + s + m), ee(m, 0.0), Zl((size_t)m * m);
+                for (int i = 0; i + 1 < m; i++) ee[i] = e[s + i];
+                if (host_tql2(m, dd.data(), ee.data(), Zl.data(), m) != 0) { failed = 1; return; }
+                for (int i = 0; i < m; i++) { d[s + i] = dd[i]; for (int j = 0; j < m; j++) S[(size_t)(s + i) * maxleaf + j] = Zl[(size_t)i * m + j]; }
+                leaf_start[l] = s; leaf_size[l] = m;
+                for (int i = 0; i < m; i++) leaf_of_row[s + i] = l;
+            }
+        };
+        const int nthr = (int)std::max(1u, std::min(8u, std::min((unsigned)nleaf, std::thread::hardware_concurrency())));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthr; t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        if (failed) { set_error("stedc: leaf QL did not converge"); return PG_EINVAL; }
     }
     PG_HIP(hipMemsetAsync(wk.Qa, 0, (size_t)n * n * 8, st));
     PG_HIP(hipMemsetAsync(wk.Qb, 0, (size_t)n * n * 8, st));
@@ -676,11 +716,12 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
     scatter_leaves_kernel<<<(unsigned)(((size_t)n * maxleaf + 255) / 256), 256, 0, st>>>(n, maxleaf, wk.S, wk.ibuf, wk.ibuf + n, wk.ibuf + 2 * n, wk.Qa);
     PG_HIP(hipGetLastError());
     PG_HIP(hipStreamSynchronize(st));   // host staging buffers go out of scope below
+    mark("leaves", nleaf, maxleaf);
 
     double *Qin = wk.Qa, *Qout = wk.Qb;
     std::vector<int> blocks(bs);   // boundaries of the current level
     std::vector<double> zhost(n), dnew(n);
-    std::vector<int> zrow(n), colbuf(n);
+    std::vector<int> zrow(n), colbuf(n), rpbuf(n, 0);
     while (blocks.size() > 2) {
         const int nb = (int)blocks.size() - 1;
         std::vector<MergePlan> plans;
@@ -698,6 +739,7 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
         for (auto &mp : plans) {
             plan_merge(mp, d.data() + mp.s, zhost.data() + mp.s, e[mp.s + mp.n1 - 1]);
             for (int i = 0; i < mp.nm; i++) colbuf[mp.s + i] = mp.col[i];
+            for (int i = 0; i < mp.k; i++) rpbuf[mp.s + i] = mp.rowpos[i];
             rot_total += mp.rots.size();
         }
         std::vector<Rot> allrots; allrots.reserve(rot_total + 1);
@@ -707,6 +749,7 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
             for (int i = 0; i < mp.k; i++) { dlw[mp.s + i] = mp.dl[i]; dlw[(size_t)n + mp.s + i] = mp.w[i]; }
         }
         PG_HIP(hipMemcpyAsync(wk.ibuf + n, colbuf.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        PG_HIP(hipMemcpyAsync(wk.ibuf + 2 * n, rpbuf.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));   // (the leaf tables are done with)
         if (!allrots.empty()) PG_HIP(hipMemcpyAsync(wk.rots, allrots.data(), allrots.size() * sizeof(Rot), hipMemcpyHostToDevice, st));
         PG_HIP(hipMemcpyAsync(wk.dl, dlw.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
         PG_HIP(hipMemcpyAsync(wk.w, dlw.data() + n, (size_t)n * 8, hipMemcpyHostToDevice, st));
@@ -719,10 +762,20 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
             }
             permute_cols_kernel<<<(unsigned)(((size_t)nm * nm + 255) / 256), 256, 0, st>>>(n, s, nm, k, Qin, wk.ibuf + n + s, wk.Tp, Qout);
             if (k > 0) {
-                secular_kernel<<<(k + 3) / 4, 256, 0, st>>>(k, wk.dl + s, wk.w + s, mp.rho, wk.Um, wk.dnew + s);
-                zhat_kernel<<<(k + 3) / 4, 256, 0, st>>>(k, wk.dl + s, wk.w + s, wk.Um, wk.zh);
-                uvec_kernel<<<(k + 63) / 64, 256, 0, st>>>(k, wk.zh, wk.Um);
-                int rc = dgemm(ctx, false, nm, k, k, 1.0, wk.Tp, k, wk.Um, k, 0.0, Qout + (size_t)s * n + s, n);
+                const int *rp = wk.ibuf + 2 * n + s;
+                secular_kernel<<<(k + 3) / 4, 256, 0, st>>>(k, wk.dl + s, wk.w + s, mp.rho, rp, wk.Um, wk.dnew + s);
+                zhat_kernel<<<(k + 3) / 4, 256, 0, st>>>(k, wk.dl + s, wk.w + s, rp, wk.Um, wk.zh);
+                uvec_kernel<<<(k + 63) / 64, 256, 0, st>>>(k, wk.zh, rp, wk.Um);
+                // Q_new = [Q1 0; 0 Q2] U: the upper rows only meet the columns of types 1, 2 (slots [0, k1+k2)), the lower rows
+                // those of types 2, 3 (slots [k1, k))
+                const int n1 = mp.n1, n2 = nm - mp.n1, k12 = mp.k1 + mp.k2, k23 = k - mp.k1;
+                double *Ctop = Qout + (size_t)s * n + s, *Cbot = Qout + (size_t)(s + n1) * n + s;
+                int rc = PG_OK;
+                if (k12 > 0) rc = dgemm(ctx, false, n1, k, k12, 1.0, wk.Tp, k, wk.Um, k, 0.0, Ctop, n);
+                else PG_HIP(hipMemset2DAsync(Ctop, (size_t)n * 8, 0, (size_t)k * 8, (size_t)n1, st));
+                if (rc) return rc;
+                if (k23 > 0) rc = dgemm(ctx, false, n2, k, k23, 1.0, wk.Tp + (size_t)n1 * k + mp.k1, k, wk.Um + (size_t)mp.k1 * k, k, 0.0, Cbot, n);
+                else PG_HIP(hipMemset2DAsync(Cbot, (size_t)n * 8, 0, (size_t)k * 8, (size_t)n2, st));
                 if (rc) return rc;
             }
             PG_HIP(hipGetLastError());
@@ -741,6 +794,7 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
             for (int i = 0; i < mp.k; i++) d[mp.s + i] = dnew[mp.s + i];
             for (int i = mp.k; i < mp.nm; i++) d[mp.s + i] = mp.ddefl[i - mp.k];
         }
+        { int ksum = 0; for (auto &mp : plans) ksum += mp.k; mark("level", (int)plans.size(), ksum); }
         blocks.swap(nblocks);
         std::swap(Qin, Qout);
     }
@@ -921,6 +975,17 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
     // eigenvector e_N and is dropped — and the even-n symmetric symv (half the HBM bytes, 16-byte loads) serves every n.
     const int n = (n0 > 1 && (n0 & 1)) ? n0 + 1 : n0;
     hipStream_t st = ctx->stream;
+    // PG_SYEVD_TIMING=1: phase wall times on stderr (each mark synchronises the stream: diagnostic runs only)
+    const bool timing = getenv("PG_SYEVD_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        const double t = now();
+        fprintf(stderr, "[pg_syevd_dev n=%d] %-16s %8.1f ms\n", n0, what, (t - t_prev) * 1e3);
+        t_prev = t;
+    };
     SytrdWork w;
     StedcWork wk;
     double *G = nullptr, *T = nullptr, *W = nullptr, *W2 = nullptr, *dev_ev = nullptr;
@@ -939,6 +1004,7 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
     for (int k = 0; k < nbuf && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
     if (!rc) rc = stedc_alloc(n, wk);
     if (rc) { cleanup(); return rc; }
+    mark("allocate");
     std::vector<double> hd(n), he(n, 0.0), ev;
     double *Z = nullptr;
     if (n == 1) {
@@ -962,8 +1028,11 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
             hd[n - 1] = top + std::max(1.0, fabs(top));
         }
     }
+    mark("tridiagonalise");
     if (!rc) rc = stedc_device(ctx, n, hd.data(), he.data(), ev, wk, &Z);
+    mark("divide&conquer");
     if (!rc && n > 1) rc = backtransform_device(ctx, n, w.Vall, w.tau, Z, G, T, W, W2);
+    mark("back-transform");
     if (!rc) {
         hipError_t e1 = hipMemcpyAsync(dev_ev, ev.data(), (size_t)n0 * 8, hipMemcpyHostToDevice, st);
         if (e1 != hipSuccess) rc = PG_EHIP;
@@ -974,6 +1043,8 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
         }
         if (rc == PG_EHIP) set_error("pg_syevd_dev: output stage failed");
     }
+    mark("outputs");
     cleanup();   // synchronises the stream: outputs are complete on return
+    mark("free");
     return rc;
 }
