@@ -130,6 +130,11 @@ int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, con
 int pg_rotate_geno_i8_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const void *X8_n_by_p, int is_unsigned, int64_t ldX,
                           float *Xr, int64_t ldx, void *work, int *is_geno);
 int pg_cast_i8_f32_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *X8_n_by_p, int is_unsigned, int64_t ldX, float *Xf, int64_t ldXf);
+/* ... and for float64 X (numpy's default): the reference's X.astype(np.float32) is a per-element round-to-nearest, which the
+ * kernels apply as they read the block — no host-side float32 copy of the matrix. */
+int pg_rotate_geno_f64_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const double *X_n_by_p, int64_t ldX, float *Xr,
+                           int64_t ldx, void *work, int *is_geno);
+int pg_cast_f64_f32_dev(pg_ctx *ctx, int64_t n, int64_t p, const double *X_n_by_p, int64_t ldX, float *Xf, int64_t ldXf);
 /* The same rotation straight from a PLINK .bed block (the format the reference's callers read with pysnptools.Bed,
  * experiments/benchmarks/benchmarks.py:233-239): bed = device copy of p SNP records of ldb >= ceil(n/4) bytes (SNP-major,
  * 2 bits per sample: 00 hom A1, 01 missing, 10 het, 11 hom A2).  Dosage = copies of A2 (count_a1 = 0, pysnptools

@@ -17,7 +17,7 @@ SYMBOLS = [
     "pg_ctx_destroy", "pg_ctx_sync", "pg_ctx_device", "pg_malloc", "pg_free", "pg_memcpy_h2d", "pg_memcpy_d2h",
     "pg_memset", "pg_memcpy2d_h2d", "pg_event_create", "pg_event_destroy", "pg_event_record", "pg_event_elapsed_ms",
     "pg_kinship_dev", "pg_geno_prep_bytes", "pg_geno_work_bytes", "pg_geno_prep_dev", "pg_rotate_geno_dev", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev", "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev",
-    "pg_precompute_mat_dev", "pg_newton_dev", "pg_reml_scalars_dev", "pg_rotate_bed_dev", "pg_rotate_geno_i8_dev", "pg_cast_i8_f32_dev", "pg_assoc_multi",
+    "pg_precompute_mat_dev", "pg_newton_dev", "pg_reml_scalars_dev", "pg_rotate_bed_dev", "pg_rotate_geno_i8_dev", "pg_cast_i8_f32_dev", "pg_assoc_multi", "pg_rotate_geno_f64_dev", "pg_cast_f64_f32_dev",
 ]
 
 
@@ -71,6 +71,10 @@ def load():
     L.pg_rotate_geno_i8_dev.restype = i32
     L.pg_cast_i8_f32_dev.argtypes = [vp, i64, i64, vp, i32, i64, vp, i64]
     L.pg_cast_i8_f32_dev.restype = i32
+    L.pg_rotate_geno_f64_dev.argtypes = [vp, i64, i64, vp, vp, i64, vp, i64, vp, C.POINTER(i32)]
+    L.pg_rotate_geno_f64_dev.restype = i32
+    L.pg_cast_f64_f32_dev.argtypes = [vp, i64, i64, vp, i64, vp, i64]
+    L.pg_cast_f64_f32_dev.restype = i32
     L.pg_memcpy2d_h2d.argtypes = [vp, vp, sz, vp, sz, sz, sz]
     L.pg_event_create.argtypes = [vp, C.POINTER(vp)]
     L.pg_event_destroy.argtypes = [vp, vp]

@@ -588,6 +588,23 @@ extern "C" int pg_rotate_geno_i8_dev(pg_ctx *ctx, int64_t n, int64_t p, const vo
                        : rotate_geno_any<signed char>(ctx, n, p, Uprep, (const signed char *)X8, ldX, Xr, ldx, work, is_geno_host);
 }
 
+// ... and for float64 X (numpy's default dtype; the reference's X.astype(np.float32), lmm/lmm.py:121-122, is a round-to-nearest
+// conversion per element — the same one the kernels apply when they read the block): no host-side copy of the matrix.
+extern "C" int pg_rotate_geno_f64_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const double *X, int64_t ldX, float *Xr, int64_t ldx,
+                                      void *work, int *is_geno_host)
+{
+    return rotate_geno_any<double>(ctx, n, p, Uprep, X, ldX, Xr, ldx, work, is_geno_host);
+}
+extern "C" int pg_cast_f64_f32_dev(pg_ctx *ctx, int64_t n, int64_t p, const double *X, int64_t ldX, float *Xf, int64_t ldXf)
+{
+    PG_REQUIRE(ctx && X && Xf && n > 0 && p > 0 && ldX >= p && ldXf >= p, "pg_cast_f64_f32_dev: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    dim3 grid((unsigned)((p + 255) / 256), (unsigned)(n < 65535 ? n : 65535));
+    cast_to_f32_kernel<double><<<grid, 256, 0, ctx->stream>>>(n, p, X, ldX, Xf, ldXf);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
 // float32 image of an 8-bit block (the fallback input of pg_rotate_dev / pg_transpose_dev for blocks that do not qualify)
 extern "C" int pg_cast_i8_f32_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *X8, int is_unsigned, int64_t ldX, float *Xf, int64_t ldXf)
 {

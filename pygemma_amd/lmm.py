@@ -91,7 +91,8 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
             ctx0.sync()
             packed = isinstance(X, PackedBed)
             x8 = (not packed) and X.dtype in (np.int8, np.uint8)
-            esz = 1 if x8 else 4
+            x64 = (not packed) and X.dtype == np.float64
+            esz = 1 if x8 else (8 if x64 else 4)
             pb_max = max(256, int(_BATCH_BYTES // (12 * ldx)) // 256 * 256)   # raw block + rotated block + two fp16 planes
             pb_max = min(pb_max, _BATCH_SNPS, b - a)
             ldX = (pb_max + 15) // 16 * 16
@@ -132,7 +133,15 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
                             else:
                                 _lib.check(L.pg_memcpy2d_h2d(ctx.handle, dX.ptr, ldX * esz, X.ctypes.data + esz * s, p * esz, pb * esz, n),
                                            "pg_memcpy2d_h2d")
-                                if x8:
+                                if x64:
+                                    is_geno = C.c_int(0)
+                                    _lib.check(L.pg_rotate_geno_f64_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx, dwork.ptr,
+                                                                        C.byref(is_geno)), "pg_rotate_geno_f64_dev")
+                                    if not is_geno.value:
+                                        dXf = dXf or ctx.alloc(n * ldX * 4)
+                                        _lib.check(L.pg_cast_f64_f32_dev(ctx.handle, n, pb, dX.ptr, ldX, dXf.ptr, ldX), "pg_cast_f64_f32_dev")
+                                        _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dXf.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
+                                elif x8:
                                     is_geno = C.c_int(0)
                                     _lib.check(L.pg_rotate_geno_i8_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, int(X.dtype == np.uint8), ldX,
                                                                        dXr.ptr, ldx, dwork.ptr, C.byref(is_geno)), "pg_rotate_geno_i8_dev")
@@ -205,7 +214,9 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
         Y = Y.astype(np.float32).reshape(-1, 1)              # lmm.py:115-116
     if W.dtype != np.float32:
         W = W.astype(np.float32)                             # lmm.py:118-119
-    x8 = (not packed) and eigen and X.dtype in (np.int8, np.uint8)   # stays 8-bit up to the device: same values as the cast below
+    # int8/uint8/float64 X stays as it is up to the device when it is rotated there: the kernels convert each element to
+    # float32 as they read it, which is what the cast below does (round to nearest) — no host copy of the matrix
+    x8 = (not packed) and eigen and X.dtype in (np.int8, np.uint8, np.float64)
     if not packed and not x8 and X.dtype != np.float32:
         X = X.astype(np.float32)                             # lmm.py:121-122
     if Z is not None:
@@ -256,7 +267,7 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     if not disable_checks:
         # lmm.py:253-256 (the reference tests the rotated arrays; a NaN anywhere in a raw column makes that
         # whole rotated column NaN, so testing the inputs raises in exactly the same cases)
-        if (not packed and not x8 and np.isnan(X).any()) or np.isnan(Yr).any() or np.isnan(Wr).any():
+        if (not packed and X.dtype.kind == 'f' and np.isnan(X).any()) or np.isnan(Yr).any() or np.isnan(Wr).any():
             raise ValueError("NaNs present in data")
 
     _log(verbose, f"Running {p} SNPs with {n} individuals on {ndev} GPU(s)...")

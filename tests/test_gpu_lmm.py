@@ -139,9 +139,9 @@ def test_checkpoint_restart(tmp_path, monkeypatch):
         lmm.pygemma(Y, X[:, :700], W, d, eigen=False, checkpoint=ck)
 
 
-@pytest.mark.parametrize("dtype", [np.int8, np.uint8])
+@pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.float64])
 def test_pygemma_int8_genotypes_match_float_input(dtype):
-    """8-bit genotype matrices go to the device as they are (the reference would cast them to float32 first, lmm.py:121-122):
+    """8-bit and float64 genotype matrices go to the device as they are (the reference would cast them to float32 first, lmm.py:121-122):
     same results as the float32 call; a block that is not genotype-valued (0..5 dosages) takes the cast + fp32 path."""
     from pygemma_amd import lmm, synth
     rng = np.random.default_rng(21)
@@ -156,10 +156,14 @@ def test_pygemma_int8_genotypes_match_float_input(dtype):
     for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
         assert (a[col].to_numpy() == b[col].to_numpy()).all(), col     # same codes, same planes, same kernel: identical
     G2 = rng.integers(0, 6, size=(n, p)).astype(dtype)                   # not genotype-valued
+    if dtype == np.float64:
+        G2 = G2 + rng.uniform(-0.3, 0.3, G2.shape)                        # dosages with more digits than float32 holds
+        G2[7, 3] = np.nan                                                 # and a NaN: that block takes the cast + fp32 kernel
     a = lmm.pygemma(y, G2, W, K)
     b = lmm.pygemma(y, G2.astype(np.float32), W, K)
     for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
-        assert (a[col].to_numpy() == b[col].to_numpy()).all(), col
+        x, z = a[col].to_numpy(), b[col].to_numpy()
+        assert ((x == z) | (np.isnan(x) & np.isnan(z))).all(), col
 
 
 @pytest.mark.parametrize("tag", ["imp", "dos"])
