@@ -221,7 +221,8 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
         X = X.astype(np.float32)                             # lmm.py:121-122
     if Z is not None:
         K = np.asarray(Z) @ K @ np.asarray(Z).T              # lmm.py:124-125
-    if K.dtype != np.float32:
+    k64 = eigen and K.dtype == np.float64                    # rounded to float32 on the device instead (same values, no host copy)
+    if K.dtype != np.float32 and not k64:
         K = K.astype(np.float32)                             # lmm.py:127-128
     if not packed:
         X = np.ascontiguousarray(X)
@@ -242,7 +243,14 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
             raise ValueError(f"K must be ({n},{n}) when eigen=True, got {K.shape}")
         ectx = _lib.Context(0)
         try:
-            dK = ectx.to_device(K)
+            if k64:
+                dK64 = ectx.to_device(np.ascontiguousarray(K))
+                dK = ectx.alloc(n * n * 4)
+                _lib.check(L.pg_cast_f64_f32_dev(ectx.handle, n, n, dK64.ptr, n, dK.ptr, n), "pg_cast_f64_f32_dev")   # lmm.py:127-128
+                ectx.sync()
+                dK64.free()
+            else:
+                dK = ectx.to_device(K)
             dev, dU0 = ectx.alloc(n * 4), ectx.alloc(n * n * 4)
             _lib.check(L.pg_syevd_dev(ectx.handle, n, dK.ptr, dev.ptr, dU0.ptr, None, None), "pg_syevd_dev")
             dK.free()

@@ -194,3 +194,19 @@ def test_pygemma_tier_c_imputed_and_dosage_inputs(tag):
         assert np.quantile(eb, 0.99) <= max(2.0 * np.quantile(er, 0.99), 5e-6), (col, eb.max(), er.max())
     relp = np.abs(df["p_wald"].to_numpy() - z[f"{tag}_p_wald"]) / z[f"{tag}_p_wald"]
     assert (relp <= 1e-3).mean() >= 0.99
+
+
+def test_pygemma_float64_K_rounded_on_device():
+    """K handed over as float64 (numpy's default) gives exactly the results of K.astype(float32) (lmm/lmm.py:127-128)."""
+    from pygemma_amd import lmm, synth
+    rng = np.random.default_rng(8)
+    n, p = 200, 90
+    GK = synth.genotypes(rng, n, 2 * n, np.float64)
+    K64 = GK @ GK.T / (2 * n)
+    X = synth.genotypes(rng, n, p)
+    W = np.ones((n, 1), np.float32)
+    y = rng.standard_normal((n, 1)).astype(np.float32)
+    a = lmm.pygemma(y, X, W, K64)
+    b = lmm.pygemma(y, X, W, K64.astype(np.float32))
+    for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
+        assert (a[col].to_numpy() == b[col].to_numpy()).all(), col
