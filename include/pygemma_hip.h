@@ -32,7 +32,7 @@ extern "C" {
 #define PG_ENOTSUP (-95)    /* configuration not supported by this build                */
 #define PG_ENODEV (-19)     /* no usable GPU                                            */
 
-#define PG_MAX_COVARIATES 12 /* c supported by the register-resident Gram kernels        */
+#define PG_MAX_COVARIATES 20 /* c supported by the register-resident Gram kernels        */
 
 typedef struct pg_ctx pg_ctx; /* one per (process, GPU): device id, stream, scratch      */
 

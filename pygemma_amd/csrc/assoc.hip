@@ -37,6 +37,9 @@ constexpr int WPB = 4;    // wavefronts (= SNPs) per workgroup
 #ifndef PG_PFD
 #define PG_PFD 2            // prefetch ring depth
 #endif
+#ifndef PG_CHUNK_MIN_NP
+#define PG_CHUNK_MIN_NP 80   // more Gram entries than this (c >= 11): slot-chunked passes (measured: c=10 is still faster un-chunked)
+#endif
 #ifndef PG_SCAN_NV
 #define PG_SCAN_NV 96        // decade-scan accumulators per pass (x-entries of as many lambdas as fit)
 #endif
@@ -202,6 +205,10 @@ template <int C> struct Shape {
     static constexpr int NP = M * (M + 1) / 2;  // lower-triangle entries
     static constexpr int SLOTS = (NP + 63) / 64;               // Gram entries owned per lane
     static constexpr int NV0 = NP < 64 ? NP : 64, NV1 = NP > 64 ? NP - 64 : 0;
+    // entries of slot sl: [64 sl, 64 sl + slot_nv(sl)).  CHUNKED: one slot and one power per pass over n (64 accumulators),
+    // which fits 2 waves/SIMD at any c; below PG_CHUNK_MIN_NP all entries of one or more powers share a pass.
+    static constexpr int slot_nv(int sl) { return (NP - 64 * sl) < 64 ? (NP - 64 * sl) : 64; }
+    static constexpr bool CHUNKED = NP > PG_CHUNK_MIN_NP;
     // scan: decade lambdas handled per pass
     // (two reduce-scatters of <= 64 and <= 32 values; PG_SCAN_NV caps the per-pass accumulators: 2 VGPRs each
     // — measured: 96 is best for c >= 3, 64 for c <= 2 where one more lambda per pass starts to spill)
@@ -242,23 +249,15 @@ __device__ __forceinline__ double reduce_scatter(double (&v)[NVP], int lane)
 
 // NP per-lane partials (lower-triangle entries) -> one owned entry per lane and slot: slot 0 holds entry
 // (lane % NVP0) of entries [0,64), slot 1 entry 64 + (lane % NVP1).
-template <int C>
+template <int C, int SL = 0>
 __device__ __forceinline__ void scatter_entries(const double (&acc)[Shape<C>::NP], int lane, double (&out)[Shape<C>::SLOTS])
 {
-    constexpr int NV0 = Shape<C>::NV0, NV1 = Shape<C>::NV1, NVP0 = next_pow2(NV0);
-    {
-        double t[NVP0];
+    constexpr int NV = Shape<C>::slot_nv(SL), NVP = next_pow2(NV);
+    double t[NVP];
 #pragma unroll
-        for (int k = 0; k < NVP0; k++) t[k] = (k < NV0) ? acc[k] : 0.0;
-        out[0] = reduce_scatter<NVP0>(t, lane);
-    }
-    if constexpr (NV1 > 0) {
-        constexpr int NVP1 = next_pow2(NV1);
-        double t[NVP1];
-#pragma unroll
-        for (int k = 0; k < NVP1; k++) t[k] = (k < NV1) ? acc[64 + k] : 0.0;
-        out[1] = reduce_scatter<NVP1>(t, lane);
-    }
+    for (int k = 0; k < NVP; k++) t[k] = (k < NV) ? acc[64 * SL + k] : 0.0;
+    out[SL] = reduce_scatter<NVP>(t, lane);
+    if constexpr (SL + 1 < Shape<C>::SLOTS) scatter_entries<C, SL + 1>(acc, lane, out);
 }
 
 // which Gram entries a lane owns
@@ -267,12 +266,11 @@ template <int C> struct Own {
     bool valid[Shape<C>::SLOTS];
     __device__ __forceinline__ void init(int lane)
     {
-        constexpr int NP = Shape<C>::NP, NV0 = Shape<C>::NV0, NV1 = Shape<C>::NV1;
 #pragma unroll
         for (int sl = 0; sl < Shape<C>::SLOTS; sl++) {
-            const int idx = (sl == 0) ? (lane % next_pow2(NV0)) : 64 + (lane % next_pow2(NV1 > 0 ? NV1 : 1));
-            valid[sl] = (sl == 0) ? (idx < NV0) : (idx < NP);
-            e[sl] = valid[sl] ? idx : 0;
+            const int nv = Shape<C>::slot_nv(sl), k = lane % next_pow2(nv);
+            valid[sl] = k < nv;
+            e[sl] = valid[sl] ? 64 * sl + k : 0;
             int rr = 0;
             while ((rr + 1) * (rr + 2) / 2 <= e[sl]) rr++;
             r[sl] = rr; c[sl] = e[sl] - rr * (rr + 1) / 2;
@@ -285,7 +283,8 @@ template <int SLOTS>
 __device__ __forceinline__ double gather(const double (&X)[SLOTS], int es)
 {
     double v = __shfl(X[0], es & 63, 64);
-    if constexpr (SLOTS > 1) { const double w = __shfl(X[1], (es - 64) & 63, 64); v = (es < 64) ? v : w; }
+#pragma unroll
+    for (int sl = 1; sl < SLOTS; sl++) { const double w = __shfl(X[sl], es & 63, 64); v = ((es >> 6) == sl) ? w : v; }
     return v;
 }
 
@@ -457,6 +456,52 @@ __device__ __forceinline__ void gram_pass(const AssocParams &pr, const float *xr
     if constexpr (DR) { scatter_entries<C>(R, lane, Ro); t2 = bfly(s2); }
 }
 
+// One pass over the n elements for the entries of ONE slot and ONE power (PW = 1: P, 2: Q, 3: R): the per-entry arithmetic
+// and summation order are those of gram_pass (every entry is its own fma chain), only the grouping into passes differs.
+template <int C, int PW, int SL, bool HASX>
+__device__ __forceinline__ void gram_pass_slot(const AssocParams &pr, const float *xrow, float lam, int lane, float *htab_out, double &out, double &tsum)
+{
+    constexpr int M = Shape<C>::M, E0 = 64 * SL, NV = Shape<C>::slot_nv(SL), NVP = next_pow2(NV);
+    double acc[NVP];
+#pragma unroll
+    for (int k = 0; k < NVP; k++) acc[k] = 0.0;
+    double s = 0.0;
+    pipelined<Elem<C>>(pr.niter, [&](Elem<C> &e, int it) { load_elem<C, HASX>(pr, xrow, it * 64 + lane, e); },
+                       [&](const Elem<C> &cur, int it) {
+        const int i = it * 64 + lane;
+        float d, colf[M];
+        unpack_elem<C>(pr, cur, i, d, colf);
+        const float h = (i < pr.n) ? hinv_f32(lam, d) : 0.0f;
+        if (htab_out) htab_out[i] = h;
+        const double hd = (double)h, h2 = hd * hd;
+        double col[M], a[M], g[PW == 3 ? M : 1];
+#pragma unroll
+        for (int j = 0; j < M; j++) { col[j] = (double)colf[j]; a[j] = hd * col[j]; if constexpr (PW == 3) g[j] = h2 * col[j]; }
+#pragma unroll
+        for (int j = 0; j < M; j++)
+#pragma unroll
+            for (int k = 0; k <= j; k++) {
+                const int e = tri(j, k);
+                if (e >= E0 && e < E0 + NV) {
+                    if constexpr (PW == 1) acc[e - E0] = fma(a[j], col[k], acc[e - E0]);
+                    else if constexpr (PW == 2) acc[e - E0] = fma(a[j], a[k], acc[e - E0]);
+                    else acc[e - E0] = fma(g[j], a[k], acc[e - E0]);
+                }
+            }
+        if constexpr (SL == 0 && PW == 1) s += hd;
+        if constexpr (SL == 0 && PW == 3) s = fma(hd, hd, s);
+    });
+    out = reduce_scatter<NVP>(acc, lane);
+    if constexpr (SL == 0 && (PW == 1 || PW == 3)) tsum = bfly(s);
+}
+template <int C, int PW, bool HASX, int SL = 0>
+__device__ __forceinline__ void slot_passes(const AssocParams &pr, const float *xrow, float lam, int lane, float *htab_out,
+                                            double (&X)[Shape<C>::SLOTS], double &tsum)
+{
+    gram_pass_slot<C, PW, SL, HASX>(pr, xrow, lam, lane, SL == 0 ? htab_out : nullptr, X[SL], tsum);
+    if constexpr (SL + 1 < Shape<C>::SLOTS) slot_passes<C, PW, HASX, SL + 1>(pr, xrow, lam, lane, htab_out, X, tsum);
+}
+
 // Level-0 Grams at an arbitrary lambda, then the sweeps.
 template <int C, bool FULL>
 __device__ __forceinline__ void eval_specific(const AssocParams &pr, const float *xrow, float lam, int lane, const Own<C> &own, EvalOut &o)
@@ -465,7 +510,12 @@ __device__ __forceinline__ void eval_specific(const AssocParams &pr, const float
     double P[SLOTS], Q[SLOTS], R[SLOTS], t1 = 0.0, t2 = 0.0;
 #pragma unroll
     for (int sl = 0; sl < SLOTS; sl++) R[sl] = 0.0;
-    if constexpr (FULL && Shape<C>::FUSE_PQR) {
+    if constexpr (Shape<C>::CHUNKED) {
+        double tq = 0.0;
+        slot_passes<C, 1, true>(pr, xrow, lam, lane, nullptr, P, t1);
+        slot_passes<C, 2, true>(pr, xrow, lam, lane, nullptr, Q, tq);
+        if (FULL) slot_passes<C, 3, true>(pr, xrow, lam, lane, nullptr, R, t2);
+    } else if constexpr (FULL && Shape<C>::FUSE_PQR) {
         gram_pass<C, 7, true>(pr, xrow, lam, lane, nullptr, P, Q, R, t1, t2);
     } else if constexpr (Shape<C>::FUSE_PQ) {
         gram_pass<C, 3, true>(pr, xrow, lam, lane, nullptr, P, Q, R, t1, t2);
@@ -491,7 +541,11 @@ __global__ __launch_bounds__(64) void setup_tabs_kernel(AssocParams pr)
     Own<C> own;
     own.init(lane);
     double P[SLOTS], Q[SLOTS], R[SLOTS], t1 = 0.0, t2 = 0.0;
-    if constexpr (Shape<C>::FUSE_PQ) {
+    if constexpr (Shape<C>::CHUNKED) {
+        double tq = 0.0;
+        slot_passes<C, 1, false>(pr, nullptr, lam, lane, pr.htab + (size_t)t * pr.npad, P, t1);
+        slot_passes<C, 2, false>(pr, nullptr, lam, lane, nullptr, Q, tq);
+    } else if constexpr (Shape<C>::FUSE_PQ) {
         gram_pass<C, 3, false>(pr, nullptr, lam, lane, pr.htab + (size_t)t * pr.npad, P, Q, R, t1, t2);
     } else {
         gram_pass<C, 1, false>(pr, nullptr, lam, lane, pr.htab + (size_t)t * pr.npad, P, Q, R, t1, t2);
@@ -1101,6 +1155,7 @@ extern "C" int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const floa
 #else
         PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6)
         PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10) PG_CASE(11) PG_CASE(12)
+        PG_CASE(13) PG_CASE(14) PG_CASE(15) PG_CASE(16) PG_CASE(17) PG_CASE(18) PG_CASE(19) PG_CASE(20)
 #endif
 #undef PG_CASE
         default: rc = PG_ENOTSUP;
