@@ -64,7 +64,7 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def make_inputs(n, c, B, rank, p_k):
+def make_inputs(n, c, B, rank, p_k, null=False):
     """Deterministic synthetic panel: standardised Binomial(2, maf) genotypes; K from an independent
     SNP set; y = 0.2 g0 + G_K b + e (h2 = 0.5).  K/y/W are identical on every rank, the SNP batch is per rank."""
     rng = np.random.default_rng(synth.SEED)
@@ -75,6 +75,8 @@ def make_inputs(n, c, B, rank, p_k):
     X = synth.genotypes(rngx, n, B)                                     # (n, B) float32
     g0 = synth.genotypes(np.random.default_rng(synth.SEED + 1), n, 1)[:, 0]
     y = 0.2 * g0 + GK @ b + rng.standard_normal(n).astype(np.float32) * np.sqrt(0.5)
+    if null:                                                            # the second, pure-noise phenotype
+        y = rng.standard_normal(n).astype(np.float32)
     return GK, Wm, y.astype(np.float32).reshape(-1, 1), X
 
 
@@ -88,6 +90,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16384, help="SNPs per GPU per step")
     ap.add_argument("--grid", type=int, default=0, help="1 = calc_lambda_restricted(grid=True) path")
     ap.add_argument("--cpu-sample", type=int, default=256, help="SNPs of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--null", type=int, default=0, help="1 = pure-noise phenotype (SURVEY 8d second phenotype) instead of the polygenic one")
     ap.add_argument("--fp32-rotate", type=int, default=0, help="1 = force the fp32-MFMA rotation even for genotype-valued X")
     a = ap.parse_args()
 
@@ -116,7 +119,7 @@ def main():
     # ---------------- inputs, resident in HBM before any timed region
     t0 = time.time()
     p_k = 2 * n
-    GK, Wm, y, X = make_inputs(n, c, B, rank, p_k)
+    GK, Wm, y, X = make_inputs(n, c, B, rank, p_k, null=bool(a.null))
     log(rank, f"synthetic inputs n={n} c={c} B={B} p_k={p_k}: {time.time() - t0:.1f} s (host)")
     ldx = (n + 63) // 64 * 64
     dGK = ctx.to_device(GK)
@@ -278,6 +281,7 @@ def main():
                                f"{'grid' if a.grid else 'decade-scan+Brent+Newton'} + Wald F + p on device"
                                + ("; RCCL all-gather of result rows" if world > 1 else ""),
                    "n": n, "c": c, "snps_per_gpu_per_step": B, "lambda_path": "grid" if a.grid else "brent",
+                   "phenotype": "pure noise" if a.null else "polygenic h2=0.5 + one causal SNP",
                    "parallelism": f"snp-shards x{world}"},
         "eigh_seconds": min(eigh_s),
         "eigh_note": "fp64 Householder tridiagonalisation + divide&conquer + back-transform on device, n=%d, one-time" % n,
