@@ -32,7 +32,7 @@ extern "C" {
 #define PG_ENOTSUP (-95)    /* configuration not supported by this build                */
 #define PG_ENODEV (-19)     /* no usable GPU                                            */
 
-#define PG_MAX_COVARIATES 20 /* c supported by the register-resident Gram kernels        */
+#define PG_MAX_COVARIATES 30 /* c supported by the register-resident Gram kernels (reference benchmark: up to 26) */
 
 typedef struct pg_ctx pg_ctx; /* one per (process, GPU): device id, stream, scratch      */
 
@@ -54,11 +54,56 @@ int pg_memset(pg_ctx *ctx, void *dst, int value, size_t bytes);
 /* strided host -> device copy: `height` rows of `width` bytes (a column window of a row-major host matrix) */
 int pg_memcpy2d_h2d(pg_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height);
 
+/* ---- S1: pinned host memory + asynchronous copies: streaming SNP batches and precomputed eigenvectors from the host
+ * (BASELINE configs 4-5).  The reference's eigen=False caller reads raw float32 .bin files and hands the whole pre-rotated X
+ * over (experiments/large_gwas/run_pygemma.py:33-65); here X is read straight out of pinned memory by the DMA engines, batch
+ * by batch, while the previous batch computes.
+ *   pg_host_alloc/free        : hipHostMalloc'd (portable) buffer — e.g. the array a caller np.fromfile()s its .bin into
+ *   pg_host_register/unregister: pin a caller-owned range in place
+ *   pg_memcpy*_async          : enqueue on the context's stream and return (host side should be pinned; pageable memory
+ *                               makes the runtime stage the copy and blocks)
+ *   pg_stage_rows             : host-side gather of a column window into a (pinned) staging buffer with nthreads threads —
+ *                               the pageable -> pinned leg for callers whose X is an ordinary NumPy array */
+int pg_host_alloc(pg_ctx *ctx, size_t bytes, void **hptr);
+int pg_host_free(pg_ctx *ctx, void *hptr);
+int pg_host_register(pg_ctx *ctx, void *hptr, size_t bytes);
+int pg_host_unregister(pg_ctx *ctx, void *hptr);
+int pg_memcpy_h2d_async(pg_ctx *ctx, void *dst, const void *src, size_t bytes);
+int pg_memcpy_d2h_async(pg_ctx *ctx, void *dst, const void *src, size_t bytes);
+int pg_memcpy_d2d_async(pg_ctx *ctx, void *dst, const void *src, size_t bytes);
+int pg_memcpy2d_h2d_async(pg_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height);
+int pg_stage_rows(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, int nthreads);
+
 /* HIP events on the context's stream (kernel timing for bench.py's roofline leg) */
 int pg_event_create(pg_ctx *ctx, void **event);
 int pg_event_destroy(pg_ctx *ctx, void *event);
 int pg_event_record(pg_ctx *ctx, void *event);
 int pg_event_elapsed_ms(pg_ctx *ctx, void *start, void *stop, float *ms); /* synchronises on `stop` */
+int pg_event_sync(pg_ctx *ctx, void *event);            /* host waits for the event                         */
+int pg_stream_wait_event(pg_ctx *ctx, void *event);     /* the context's stream waits for it (no host wait) */
+
+/* ---- H3 / SURVEY 8e: the one exchange step of the path, RCCL over xGMI called directly (librccl is dlopen'ed on first
+ * use; no PyTorch).  Replaces Pool(nproc).imap + the ordered concatenation of the per-block lists (lmm/lmm.py:378-403):
+ * a SNP block lives on one GPU; U/d/rotated y,W travel once (broadcast from the GPU that ran the eigensolver), the 32-byte
+ * result rows once at the end (all-gather in rank order = SNP order, blocks padded to ceil(p/G) rows like SampleIter's).
+ *   pg_comm_unique_id + pg_comm_init_rank : one process per GPU; rank 0 makes the 128-byte id and passes it to the other
+ *                                           ranks over any host channel (pygemma_amd/dist.py: file or TCP rendezvous)
+ *   pg_comm_init_all                      : one process, ndev GPUs, one host thread per GPU issuing the collectives
+ * Collectives are enqueued on the stream of the context the communicator was made with. */
+typedef struct pg_comm pg_comm;
+#define PG_COMM_ID_BYTES 128
+int pg_comm_unique_id(void *id128);
+int pg_comm_init_rank(pg_ctx *ctx, int nranks, int rank, const void *id128, pg_comm **out);
+int pg_comm_init_all(int ndev, pg_ctx *const *ctxs, pg_comm **out /* [ndev] */);
+int pg_comm_destroy(pg_comm *comm);
+int pg_comm_size(const pg_comm *comm);
+int pg_comm_rank(const pg_comm *comm);
+int pg_comm_broadcast_dev(pg_comm *comm, void *buf, size_t bytes, int root);                      /* in place */
+int pg_comm_allgather_dev(pg_comm *comm, const void *send, void *recv, size_t bytes_per_rank);
+int pg_comm_allreduce_f64_dev(pg_comm *comm, double *buf, size_t count, int op_max);              /* in place; sum or max */
+int pg_comm_barrier(pg_comm *comm);                                                               /* + stream sync */
+int pg_comm_group_start(void);
+int pg_comm_group_end(void);
 
 /* ---- H3-H10: the per-SNP operator -------------------------------------------------------
  * Replaces calculate() (lmm/lmm.py:461-495) and everything under it: calc_lambda_restricted
@@ -87,8 +132,8 @@ int pg_assoc(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const flo
              double *pval, unsigned long long *stats2);
 
 /* pg_assoc over several GPUs of the node: contiguous blocks of ceil(p/ngpu) SNP columns like the reference's
- * SampleIter (lmm/lmm.py:427-434) — one host thread and one context per GPU, outputs in SNP order.  No collective is
- * needed: SNPs are independent and every GPU copies its block of results into its slice of the host arrays. */
+ * SampleIter (lmm/lmm.py:427-434) — one host thread and one context per GPU; the 32-byte result rows of all blocks are
+ * all-gathered over RCCL (pg_comm_*) and leave the node's GPU 0 in SNP order with one copy per column. */
 int pg_assoc_multi(int ngpu, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
                    const float *X_n_by_p, int grid, float *beta, float *se, float *tau, float *lambda, double *F, double *pval);
 
@@ -108,13 +153,14 @@ int pg_rotate_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU
 
 /* ---- N4: rotation fast path for GENOTYPE columns (each column of the block takes <= 3 equally spaced
  * values: hard calls 0/1/2, raw or centred/standardised).  U'x = v0 (U'1) + dx (U'code): the codes are exact in fp16,
- * U (scaled by a power of two) is split once into two fp16 planes (residual <= 2^-24 |U|, the size of float32's own
- * rounding of U), the products are exact in fp32 and accumulate in fp32 on the fp16 MFMA pipe
+ * U (scaled by a power of two) is split once into two fp16 planes by round-to-nearest (11 + 11 significant bits plus
+ * the sign of the second plane: residual <= 2^-23 |U| in the worst case, 2^-24 |U| typically — within one bit of float32's
+ * own rounding of U), the products are exact in fp32 and accumulate in fp32 on the fp16 MFMA pipe
  * (same error class as pg_rotate_dev / the reference's sgemm, 8x fewer matrix cycles).  A column may also hold ONE other
  * value anywhere (missing calls imputed with the column mean, experiments/benchmarks/benchmarks.py:243-244): such blocks
  * take a second, accumulating pass on the 0/1 indicator plane.
  * Finite blocks that are not genotype-valued (imputed dosages, any float X) take the same GEMM with X itself split into two
- * fp16 planes (per-column power-of-two scale, residual <= 2^-24 |x|): two passes, still 3x faster than pg_rotate_dev.
+ * fp16 planes (per-column power-of-two scale, residual <= 2^-23 |x|): two passes, still 3x faster than pg_rotate_dev.
  *   pg_geno_prep_dev   : once per U -> Uprep (pg_geno_prep_bytes(n) bytes, device)
  *   pg_rotate_geno_dev : per SNP block; Xr written (same layout as pg_rotate_dev) and *is_geno = 1 (genotype-valued block)
  *                        or 2 (general finite block, split path); *is_geno = 0 and Xr untouched when the block holds a NaN
@@ -145,8 +191,14 @@ int pg_rotate_bed_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, cons
 
 /* ---- N3: relatedness matrix from standardised genotypes, K = G G' / p_k
  * (experiments/animal_gwas/run_gwas.py:45-55, tests/test_pygemma.py:184-192).  Gt is the SNP-major (p_k x ldg)
- * image of G (n x p_k), e.g. from pg_transpose_dev; K (n x n, row-major) float32, both triangles written. */
+ * image of the standardised G (n x p_k), e.g. from pg_transpose_dev; K (n x n, row-major) float32, both triangles written
+ * (computed as a syrk: tiles on or below the diagonal only). */
 int pg_kinship_dev(pg_ctx *ctx, int64_t n, int64_t p_k, const float *Gt, int64_t ldg, float *K);
+/* The same straight from the (n x p) genotype matrix G (row-major, row stride ldG), as calculate_genetic_relatedness_matrix
+ * builds it (run_gwas.py:46-56): standardize != 0 centres every column and divides by its population standard deviation
+ * (fp64 statistics, sd == 0 -> 1) on the device; then a lower-triangle syrk on the fp32 MFMA pipe (the upper triangle is the
+ * mirror, bit-symmetric).  K can go straight into pg_syevd_dev. */
+int pg_kinship_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *G, int64_t ldG, int standardize, float *K);
 
 /* ---- H1: eigendecomposition of K (lmm/lmm.py:151-162 / :196-207, scipy.linalg.eigh = LAPACK ssyevr)
  * Reads the LOWER triangle of row-major K (n x n, float32, device).  Computes in fp64; delivers ascending
@@ -172,6 +224,16 @@ int pg_precompute_mat_dev(pg_ctx *ctx, int64_t n, int ctot, float lam, const flo
 int pg_newton_dev(pg_ctx *ctx, int64_t n, int ctot, float lam, float lam_min, float lam_max, const float *d,
                   const float *Wx, const float *y, float *root);
 int pg_reml_scalars_dev(pg_ctx *ctx, int64_t n, int ctot, const float *args8, float *out3);
+
+/* ---- Test hooks of the eigensolver's stages (tests/test_gpu_syevd.py, tools/bench_dgemm.py): not part of the drop-in
+ * surface, exported so that each stage can be checked against host LAPACK on its own.
+ * pgx_dgemm_dev : C = alpha op(A) B + beta C in fp64 on v_mfma_f64_16x16x4_f64 (row-major; transA: A is K x M)
+ * pgx_sytrd_dev : Householder tridiagonalisation of the lower triangle of float32 K -> d, e, tau, reflectors (device)
+ * pgx_stedc_dev : divide & conquer on a tridiagonal given on the host -> eigenvalues (host), eigenvectors Z (device) */
+int pgx_dgemm_dev(pg_ctx *ctx, int transA, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                  const double *B, int64_t ldb, double beta, double *C, int64_t ldc);
+int pgx_sytrd_dev(pg_ctx *ctx, int64_t n, const float *K, double *d, double *e, double *tau, double *Vall);
+int pgx_stedc_dev(pg_ctx *ctx, int64_t n, const double *d_host, const double *e_host, double *evals_host, double *Z_dev);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,11 @@ SYMBOLS = [
     "pg_memset", "pg_memcpy2d_h2d", "pg_event_create", "pg_event_destroy", "pg_event_record", "pg_event_elapsed_ms",
     "pg_kinship_dev", "pg_geno_prep_bytes", "pg_geno_work_bytes", "pg_geno_prep_dev", "pg_rotate_geno_dev", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev", "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev",
     "pg_precompute_mat_dev", "pg_newton_dev", "pg_reml_scalars_dev", "pg_rotate_bed_dev", "pg_rotate_geno_i8_dev", "pg_cast_i8_f32_dev", "pg_assoc_multi", "pg_rotate_geno_f64_dev", "pg_cast_f64_f32_dev",
+    "pg_host_alloc", "pg_host_free", "pg_host_register", "pg_host_unregister", "pg_memcpy_h2d_async", "pg_memcpy_d2h_async",
+    "pg_memcpy_d2d_async", "pg_memcpy2d_h2d_async", "pg_stage_rows", "pg_event_sync", "pg_stream_wait_event",
+    "pg_comm_unique_id", "pg_comm_init_rank", "pg_comm_init_all", "pg_comm_destroy", "pg_comm_size", "pg_comm_rank",
+    "pg_comm_broadcast_dev", "pg_comm_allgather_dev", "pg_comm_allreduce_f64_dev", "pg_comm_barrier", "pg_comm_group_start",
+    "pg_comm_group_end", "pgx_dgemm_dev", "pgx_sytrd_dev", "pgx_stedc_dev", "pg_kinship_geno_dev",
 ]
 
 
@@ -57,6 +62,8 @@ def load():
     L.pg_transpose_dev.argtypes = [vp, i64, i64, vp, i64, vp, i64]
     L.pg_rotate_dev.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp, i64]
     L.pg_kinship_dev.argtypes = [vp, i64, i64, vp, i64, vp]
+    L.pg_kinship_geno_dev.argtypes = [vp, i64, i64, vp, i64, i32, vp]
+    L.pg_kinship_geno_dev.restype = i32
     L.pg_geno_prep_bytes.argtypes = [i64]
     L.pg_geno_prep_bytes.restype = sz
     L.pg_geno_work_bytes.argtypes = [i64, i64]
@@ -85,6 +92,36 @@ def load():
     L.pg_precompute_mat_dev.argtypes = [vp, i64, i32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.pg_newton_dev.argtypes = [vp, i64, i32, f32, f32, f32, vp, vp, vp, vp]
     L.pg_reml_scalars_dev.argtypes = [vp, i64, i32, vp, vp]
+    L.pg_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.pg_host_free.argtypes = [vp, vp]
+    L.pg_host_register.argtypes = [vp, vp, sz]
+    L.pg_host_unregister.argtypes = [vp, vp]
+    L.pg_memcpy_h2d_async.argtypes = [vp, vp, vp, sz]
+    L.pg_memcpy_d2h_async.argtypes = [vp, vp, vp, sz]
+    L.pg_memcpy_d2d_async.argtypes = [vp, vp, vp, sz]
+    L.pg_memcpy2d_h2d_async.argtypes = [vp, vp, sz, vp, sz, sz, sz]
+    L.pg_stage_rows.argtypes = [vp, sz, vp, sz, sz, sz, i32]
+    L.pg_event_sync.argtypes = [vp, vp]
+    L.pg_stream_wait_event.argtypes = [vp, vp]
+    L.pg_comm_unique_id.argtypes = [vp]
+    L.pg_comm_init_rank.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+    L.pg_comm_init_all.argtypes = [i32, C.POINTER(vp), C.POINTER(vp)]
+    L.pg_comm_destroy.argtypes = [vp]
+    L.pg_comm_size.argtypes = [vp]
+    L.pg_comm_rank.argtypes = [vp]
+    L.pg_comm_broadcast_dev.argtypes = [vp, vp, sz, i32]
+    L.pg_comm_allgather_dev.argtypes = [vp, vp, vp, sz]
+    L.pg_comm_allreduce_f64_dev.argtypes = [vp, vp, sz, i32]
+    L.pg_comm_barrier.argtypes = [vp]
+    L.pgx_dgemm_dev.argtypes = [vp, i32, i64, i64, i64, C.c_double, vp, i64, vp, i64, C.c_double, vp, i64]
+    L.pgx_sytrd_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    L.pgx_stedc_dev.argtypes = [vp, i64, vp, vp, vp, vp]
+    for name in ("pg_host_alloc", "pg_host_free", "pg_host_register", "pg_host_unregister", "pg_memcpy_h2d_async", "pg_memcpy_d2h_async",
+                 "pg_memcpy_d2d_async", "pg_memcpy2d_h2d_async", "pg_stage_rows", "pg_event_sync", "pg_stream_wait_event", "pg_comm_unique_id",
+                 "pg_comm_init_rank", "pg_comm_init_all", "pg_comm_destroy", "pg_comm_size", "pg_comm_rank", "pg_comm_broadcast_dev",
+                 "pg_comm_allgather_dev", "pg_comm_allreduce_f64_dev", "pg_comm_barrier", "pg_comm_group_start", "pg_comm_group_end",
+                 "pgx_dgemm_dev", "pgx_sytrd_dev", "pgx_stedc_dev"):
+        getattr(L, name).restype = i32
     for name in ("pg_ctx_create", "pg_ctx_create_on_stream", "pg_ctx_sync", "pg_ctx_device", "pg_malloc", "pg_free",
                  "pg_memcpy_h2d", "pg_memcpy_d2h", "pg_memset", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev",
                  "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev", "pg_memcpy2d_h2d", "pg_event_create", "pg_event_destroy",
@@ -175,3 +212,72 @@ class Context:
 
 def device_count():
     return load().pg_device_count()
+
+
+# ---- pinned host memory (S1: streaming SNP batches / eigenvectors from the host) ---------------------------------------
+_pinned = {}     # base address -> nbytes of every live pinned range this process made (pinned_empty / pin)
+
+
+class _PinnedBlock:
+    """Owner of one hipHostMalloc'd range; freed when the last NumPy view of it goes away."""
+
+    def __init__(self, nbytes, device=0):
+        import weakref
+        self.ctx = Context(device)
+        p = C.c_void_p()
+        check(load().pg_host_alloc(self.ctx.handle, max(int(nbytes), 1), C.byref(p)), "pg_host_alloc")
+        self.ptr, self.nbytes = p.value, int(nbytes)
+        _pinned[self.ptr] = self.nbytes
+        self._fin = weakref.finalize(self, _PinnedBlock._release, self.ctx, self.ptr)
+
+    @staticmethod
+    def _release(ctx, ptr):
+        _pinned.pop(ptr, None)
+        try:
+            load().pg_host_free(ctx.handle, ptr)
+            ctx.close()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32, device=0):
+    """np.empty in page-locked host memory (hipHostMalloc, portable): the array to np.fromfile()/copy a genotype or
+    eigenvector matrix into so that lmm.pygemma streams it by DMA without a staging copy."""
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    blk = _PinnedBlock(nbytes, device)
+    buf = (C.c_char * max(nbytes, 1)).from_address(blk.ptr)
+    arr = np.frombuffer(buf, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
+    arr.flags.writeable = True
+    # arr.base -> memoryview -> buf: tie the block's life to the buffer object the array is based on
+    buf._pg_block = blk
+    return arr
+
+
+def pin(arr, device=0):
+    """Page-lock an existing C-contiguous NumPy array in place (hipHostRegister).  Returns a handle whose .close() unpins;
+    pinning costs ~0.1 s/GB, so it pays for arrays that are streamed more than once — otherwise let lmm.pygemma stage."""
+    assert arr.flags.c_contiguous
+    ctx = Context(device)
+    check(load().pg_host_register(ctx.handle, arr.ctypes.data, arr.nbytes), "pg_host_register")
+    _pinned[arr.ctypes.data] = arr.nbytes
+
+    class _Pin:
+        def close(self_inner):
+            if _pinned.pop(arr.ctypes.data, None) is not None:
+                load().pg_host_unregister(ctx.handle, arr.ctypes.data)
+                ctx.close()
+    return _Pin()
+
+
+def is_pinned(arr):
+    """True when the array's bytes lie inside a range pinned through this module."""
+    try:
+        from numpy.lib.array_utils import byte_bounds
+    except ImportError:          # NumPy 1.x
+        byte_bounds = np.byte_bounds
+    lo, hi = byte_bounds(arr)
+    for base, nb in list(_pinned.items()):
+        if base <= lo and hi <= base + nb:
+            return True
+    return False

@@ -98,14 +98,22 @@ int build_npsum_plan(pg_ctx *ctx, int64_t n)
     PG_HIP(hipStreamSynchronize(ctx->stream));
     if (pl.d_leaf) { (void)hipFree(pl.d_leaf); (void)hipFree(pl.d_node); (void)hipFree(pl.d_level); (void)hipFree(pl.d_chunk); }
     pl = NpSumPlan{};
-    PG_HIP(hipMalloc(&pl.d_leaf, leaf.size() * 4));
-    PG_HIP(hipMalloc(&pl.d_node, node_lr.size() * 4));
-    PG_HIP(hipMalloc(&pl.d_level, level.size() * 4));
-    PG_HIP(hipMalloc(&pl.d_chunk, chunks.size() * 4));
-    PG_HIP(hipMemcpy(pl.d_leaf, leaf.data(), leaf.size() * 4, hipMemcpyHostToDevice));
-    PG_HIP(hipMemcpy(pl.d_node, node_lr.data(), node_lr.size() * 4, hipMemcpyHostToDevice));
-    PG_HIP(hipMemcpy(pl.d_level, level.data(), level.size() * 4, hipMemcpyHostToDevice));
-    PG_HIP(hipMemcpy(pl.d_chunk, chunks.data(), chunks.size() * 4, hipMemcpyHostToDevice));
+    {
+        hipError_t e = hipMalloc(&pl.d_leaf, leaf.size() * 4);
+        if (e == hipSuccess) e = hipMalloc(&pl.d_node, node_lr.size() * 4);
+        if (e == hipSuccess) e = hipMalloc(&pl.d_level, level.size() * 4);
+        if (e == hipSuccess) e = hipMalloc(&pl.d_chunk, chunks.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(pl.d_leaf, leaf.data(), leaf.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(pl.d_node, node_lr.data(), node_lr.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(pl.d_level, level.data(), level.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(pl.d_chunk, chunks.data(), chunks.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {   // no partial plan is left behind
+            set_error("build_npsum_plan: %s", hipGetErrorString(e));
+            for (void *q : {(void *)pl.d_leaf, (void *)pl.d_node, (void *)pl.d_level, (void *)pl.d_chunk}) if (q) (void)hipFree(q);
+            pl = NpSumPlan{};
+            return e == hipErrorOutOfMemory ? PG_ENOMEM : PG_EHIP;
+        }
+    }
     pl.n = n; pl.n_leaf = n_leaf; pl.n_node = n_node; pl.n_level = maxh; pl.n_chunk = (int)chunks.size();
     return PG_OK;
 }
@@ -224,6 +232,98 @@ extern "C" int pg_memcpy2d_h2d(pg_ctx *ctx, void *dst, size_t dpitch, const void
     PG_HIP(hipStreamSynchronize(ctx->stream));
     return PG_OK;
 }
+
+// ---- S1: pinned host memory and asynchronous copies (streaming SNP batches / eigenvectors from the host, BASELINE configs 4-5;
+// the reference's eigen=False caller reads raw float32 .bin files, experiments/large_gwas/run_pygemma.py:33-65) -------------
+extern "C" int pg_host_alloc(pg_ctx *ctx, size_t bytes, void **hptr)
+{
+    PG_REQUIRE(ctx && hptr, "pg_host_alloc: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocPortable);   // portable: usable from every GPU's context
+    if (e != hipSuccess) { set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); *hptr = nullptr; return PG_ENOMEM; }
+    return PG_OK;
+}
+extern "C" int pg_host_free(pg_ctx *ctx, void *hptr)
+{
+    PG_REQUIRE(ctx, "pg_host_free: NULL ctx");
+    if (!hptr) return PG_OK;
+    PG_HIP(hipSetDevice(ctx->device));
+    PG_HIP(hipHostFree(hptr));
+    return PG_OK;
+}
+extern "C" int pg_host_register(pg_ctx *ctx, void *hptr, size_t bytes)
+{
+    PG_REQUIRE(ctx && hptr && bytes > 0, "pg_host_register: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipHostRegister(hptr, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { set_error("hipHostRegister(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); (void)hipGetLastError(); return PG_EHIP; }
+    return PG_OK;
+}
+extern "C" int pg_host_unregister(pg_ctx *ctx, void *hptr)
+{
+    PG_REQUIRE(ctx && hptr, "pg_host_unregister: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    PG_HIP(hipHostUnregister(hptr));
+    return PG_OK;
+}
+extern "C" int pg_memcpy_h2d_async(pg_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    PG_REQUIRE(ctx && (bytes == 0 || (dst && src)), "pg_memcpy_h2d_async: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
+    PG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return PG_OK;
+}
+extern "C" int pg_memcpy_d2h_async(pg_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    PG_REQUIRE(ctx && (bytes == 0 || (dst && src)), "pg_memcpy_d2h_async: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
+    PG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return PG_OK;
+}
+extern "C" int pg_memcpy2d_h2d_async(pg_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height)
+{
+    PG_REQUIRE(ctx && dst && src && dpitch >= width && spitch >= width, "pg_memcpy2d_h2d_async: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    PG_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, ctx->stream));
+    return PG_OK;
+}
+extern "C" int pg_memcpy_d2d_async(pg_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    PG_REQUIRE(ctx && (bytes == 0 || (dst && src)), "pg_memcpy_d2d_async: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
+    PG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return PG_OK;
+}
+// host-side gather of a column window (height rows of width bytes, row stride spitch) into a (pinned) staging buffer with
+// nthreads copy threads: the pageable -> pinned leg of a streamed batch, off the Python thread (ctypes drops the GIL)
+extern "C" int pg_stage_rows(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, int nthreads)
+{
+    PG_REQUIRE(dst && src && dpitch >= width && spitch >= width, "pg_stage_rows: bad arguments");
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(nthreads, 1), height));
+    auto work = [&](int t) {
+        const size_t r0 = height * t / T, r1 = height * (t + 1) / T;
+        for (size_t r = r0; r < r1; r++) memcpy((char *)dst + r * dpitch, (const char *)src + r * spitch, width);
+    };
+    if (T == 1) { work(0); return PG_OK; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+    return PG_OK;
+}
+extern "C" int pg_event_sync(pg_ctx *ctx, void *event)
+{
+    PG_REQUIRE(ctx && event, "pg_event_sync: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
+    PG_HIP(hipEventSynchronize((hipEvent_t)event));
+    return PG_OK;
+}
+extern "C" int pg_stream_wait_event(pg_ctx *ctx, void *event)
+{
+    PG_REQUIRE(ctx && event, "pg_stream_wait_event: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
+    PG_HIP(hipStreamWaitEvent(ctx->stream, (hipEvent_t)event, 0));
+    return PG_OK;
+}
 extern "C" int pg_event_create(pg_ctx *ctx, void **event)
 {
     PG_REQUIRE(ctx && event, "pg_event_create: NULL argument");
@@ -236,69 +336,80 @@ extern "C" int pg_event_create(pg_ctx *ctx, void **event)
 extern "C" int pg_event_destroy(pg_ctx *ctx, void *event)
 {
     PG_REQUIRE(ctx, "pg_event_destroy: NULL ctx");
+    PG_HIP(hipSetDevice(ctx->device));
     if (event) PG_HIP(hipEventDestroy((hipEvent_t)event));
     return PG_OK;
 }
 extern "C" int pg_event_record(pg_ctx *ctx, void *event)
 {
     PG_REQUIRE(ctx && event, "pg_event_record: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
     PG_HIP(hipEventRecord((hipEvent_t)event, ctx->stream));
     return PG_OK;
 }
 extern "C" int pg_event_elapsed_ms(pg_ctx *ctx, void *start, void *stop, float *ms)
 {
     PG_REQUIRE(ctx && start && stop && ms, "pg_event_elapsed_ms: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
     PG_HIP(hipEventSynchronize((hipEvent_t)stop));
     PG_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
     return PG_OK;
 }
 
 // host-pointer convenience around pg_assoc_dev: columns [0, p) of a host matrix X in the reference layout (n rows, row
-// stride ldX floats); the outputs are host arrays of length p
-static int assoc_host_block(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
-                            const float *X, int64_t ldX, int grid, float *beta, float *se, float *tau, float *lambda, double *F,
-                            double *pval, unsigned long long *stats2)
+// stride ldX floats) -> one device result block of `cols` >= p rows laid out [F | pval | beta | se | tau | lambda]
+// (cols f64, cols f64, 4 x cols f32 = 32 bytes per SNP: the row block the ranks exchange).  Enqueues; does not synchronise.
+struct HostBlock {
+    float *dd = nullptr, *dW = nullptr, *dy = nullptr, *dX = nullptr, *dXr = nullptr;
+    unsigned long long *dstats = nullptr;
+    void release(pg_ctx *ctx)
+    {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void *q : {(void *)dd, (void *)dW, (void *)dy, (void *)dX, (void *)dXr, (void *)dstats})
+            if (q) (void)hipFree(q);
+        *this = HostBlock{};
+    }
+};
+static int assoc_host_block(pg_ctx *ctx, HostBlock &hb, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
+                            const float *X, int64_t ldX, int grid, char *res, int64_t cols, bool want_p)
 {
     if (p == 0) return PG_OK;
     PG_HIP(hipSetDevice(ctx->device));
     const int64_t ldx = (n + 63) / 64 * 64;
-    float *dd = nullptr, *dW = nullptr, *dy = nullptr, *dX = nullptr, *dXr = nullptr, *dout = nullptr;
-    double *dF = nullptr;
-    unsigned long long *dstats = nullptr;
-    int rc = PG_OK;
-    auto cleanup = [&]() {
-        (void)hipStreamSynchronize(ctx->stream);
-        for (void *q : {(void *)dd, (void *)dW, (void *)dy, (void *)dX, (void *)dXr, (void *)dout, (void *)dF, (void *)dstats})
-            if (q) (void)hipFree(q);
-    };
-#define PG_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(_e)); cleanup(); return (_e == hipErrorOutOfMemory) ? PG_ENOMEM : PG_EHIP; } } while (0)
-    PG_TRY(hipMalloc(&dd, n * 4));
-    PG_TRY(hipMalloc(&dW, (size_t)n * (c > 0 ? c : 1) * 4));
-    PG_TRY(hipMalloc(&dy, n * 4));
-    PG_TRY(hipMalloc(&dX, (size_t)n * p * 4));
-    PG_TRY(hipMalloc(&dXr, (size_t)p * ldx * 4));
-    PG_TRY(hipMalloc(&dout, (size_t)p * 4 * 4));
-    PG_TRY(hipMalloc(&dF, (size_t)p * 2 * 8));
-    PG_TRY(hipMalloc(&dstats, 16));
-    PG_TRY(hipMemsetAsync(dstats, 0, 16, ctx->stream));
-    PG_TRY(hipMemcpyAsync(dd, d, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    PG_TRY(hipMemcpyAsync(dW, Wr, (size_t)n * c * 4, hipMemcpyHostToDevice, ctx->stream));
-    PG_TRY(hipMemcpyAsync(dy, yr, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    PG_TRY(hipMemcpy2DAsync(dX, (size_t)p * 4, X, (size_t)ldX * 4, (size_t)p * 4, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    rc = pg_transpose_dev(ctx, n, p, dX, p, dXr, ldx);
-    if (!rc) rc = pg_assoc_dev(ctx, n, c, p, dd, dW, dy, dXr, ldx, grid, dout, dout + p, dout + 2 * p, dout + 3 * p, dF,
-                               pval ? dF + p : nullptr, dstats);
-    if (rc) { cleanup(); return rc; }
-    PG_TRY(hipMemcpyAsync(beta, dout, p * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PG_TRY(hipMemcpyAsync(se, dout + p, p * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PG_TRY(hipMemcpyAsync(tau, dout + 2 * p, p * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PG_TRY(hipMemcpyAsync(lambda, dout + 3 * p, p * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PG_TRY(hipMemcpyAsync(F, dF, p * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (pval) PG_TRY(hipMemcpyAsync(pval, dF + p, p * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (stats2) PG_TRY(hipMemcpyAsync(stats2, dstats, 16, hipMemcpyDeviceToHost, ctx->stream));
-    PG_TRY(hipStreamSynchronize(ctx->stream));
+#define PG_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(_e)); return (_e == hipErrorOutOfMemory) ? PG_ENOMEM : PG_EHIP; } } while (0)
+    PG_TRY(hipMalloc(&hb.dd, n * 4));
+    PG_TRY(hipMalloc(&hb.dW, (size_t)n * (c > 0 ? c : 1) * 4));
+    PG_TRY(hipMalloc(&hb.dy, n * 4));
+    PG_TRY(hipMalloc(&hb.dX, (size_t)n * p * 4));
+    PG_TRY(hipMalloc(&hb.dXr, (size_t)p * ldx * 4));
+    PG_TRY(hipMalloc(&hb.dstats, 16));
+    PG_TRY(hipMemsetAsync(hb.dstats, 0, 16, ctx->stream));
+    PG_TRY(hipMemcpyAsync(hb.dd, d, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PG_TRY(hipMemcpyAsync(hb.dW, Wr, (size_t)n * c * 4, hipMemcpyHostToDevice, ctx->stream));
+    PG_TRY(hipMemcpyAsync(hb.dy, yr, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PG_TRY(hipMemcpy2DAsync(hb.dX, (size_t)p * 4, X, (size_t)ldX * 4, (size_t)p * 4, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
 #undef PG_TRY
-    cleanup();
+    int rc = pg_transpose_dev(ctx, n, p, hb.dX, p, hb.dXr, ldx);
+    double *F = (double *)res, *pv = F + cols;
+    float *f4 = (float *)(pv + cols);
+    if (!rc) rc = pg_assoc_dev(ctx, n, c, p, hb.dd, hb.dW, hb.dy, hb.dXr, ldx, grid, f4, f4 + cols, f4 + 2 * cols, f4 + 3 * cols, F,
+                               want_p ? pv : nullptr, hb.dstats);
+    return rc;
+}
+// rows [0, cnt) of one result block (device, `cols` rows) -> the caller's host arrays
+static int copy_block_out(pg_ctx *ctx, const char *res, int64_t cols, int64_t cnt, float *beta, float *se, float *tau, float *lambda,
+                          double *F, double *pval)
+{
+    if (cnt <= 0) return PG_OK;
+    const double *dF = (const double *)res, *dp = dF + cols;
+    const float *f4 = (const float *)(dp + cols);
+    PG_HIP(hipMemcpyAsync(F, dF, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (pval) PG_HIP(hipMemcpyAsync(pval, dp, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipMemcpyAsync(beta, f4, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipMemcpyAsync(se, f4 + cols, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipMemcpyAsync(tau, f4 + 2 * cols, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PG_HIP(hipMemcpyAsync(lambda, f4 + 3 * cols, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
     return PG_OK;
 }
 
@@ -308,12 +419,26 @@ extern "C" int pg_assoc(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d
 {
     PG_REQUIRE(ctx && d && Wr && yr && X && beta && se && tau && lambda && F, "pg_assoc: NULL argument");
     PG_REQUIRE(n >= 2 && p >= 0 && c >= 0, "pg_assoc: bad shape");
-    return assoc_host_block(ctx, n, c, p, d, Wr, yr, X, p, grid, beta, se, tau, lambda, F, pval, stats2);
+    if (p == 0) return PG_OK;
+    PG_HIP(hipSetDevice(ctx->device));
+    HostBlock hb;
+    char *res = nullptr;
+    hipError_t e = hipMalloc(&res, (size_t)p * 32);
+    if (e != hipSuccess) { set_error("pg_assoc: hipMalloc(%zu) failed: %s", (size_t)p * 32, hipGetErrorString(e)); return PG_ENOMEM; }
+    int rc = assoc_host_block(ctx, hb, n, c, p, d, Wr, yr, X, p, grid, res, p, pval != nullptr);
+    if (!rc) rc = copy_block_out(ctx, res, p, p, beta, se, tau, lambda, F, pval);
+    if (!rc && stats2 && hipMemcpyAsync(stats2, hb.dstats, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { set_error("pg_assoc: stats copy failed"); rc = PG_EHIP; }
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error("pg_assoc: stream failed: %s", hipGetErrorString(hipGetLastError())); rc = PG_EHIP; }
+    hb.release(ctx);
+    (void)hipFree(res);
+    return rc;
 }
 
 // The same over several GPUs of this node: contiguous SNP blocks of ceil(p/ngpu) columns like the reference's
-// SampleIter (lmm/lmm.py:427-434), one host thread + one context per GPU, results written in SNP order.  SNPs are
-// independent, so there is no device-to-device exchange: the gather is each GPU's copy-out into its slice of the outputs.
+// SampleIter (lmm/lmm.py:427-434), one host thread + one context per GPU.  Every GPU writes its block of 32-byte result rows
+// (padded to `cols` rows); one RCCL all-gather (pg_comm_*, xGMI) assembles the blocks in rank order = SNP order — the
+// device-side equivalent of the reference's ordered concatenation of the per-block lists (lmm/lmm.py:393,401) — and GPU 0's
+// copy goes to the caller's arrays.
 extern "C" int pg_assoc_multi(int ngpu, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
                               const float *X, int grid, float *beta, float *se, float *tau, float *lambda, double *F, double *pval)
 {
@@ -321,28 +446,61 @@ extern "C" int pg_assoc_multi(int ngpu, int64_t n, int c, int64_t p, const float
     PG_REQUIRE(n >= 2 && p >= 0 && c >= 0 && ngpu >= 1, "pg_assoc_multi: bad arguments");
     int have = 0;
     if (hipGetDeviceCount(&have) != hipSuccess || have < 1) { set_error("pg_assoc_multi: no GPU visible"); return PG_ENODEV; }
-    const int G = (int)std::min<int64_t>(std::min(ngpu, have), std::max<int64_t>(p, 1));
+    if (p == 0) return PG_OK;
+    const int G = (int)std::min<int64_t>(std::min(ngpu, have), p);
     const int64_t cols = (p + G - 1) / G;
+    std::vector<pg_ctx *> ctxs(G, nullptr);
+    std::vector<pg_comm *> comms(G, nullptr);
+    std::vector<char *> res(G, nullptr), all(G, nullptr);
+    std::vector<HostBlock> hbs(G);
     std::vector<int> rcs(G, PG_OK);
     std::vector<std::string> msgs(G);
+    int rc = PG_OK;
+    auto teardown = [&]() {
+        for (int g = 0; g < G; g++) {
+            if (!ctxs[g]) continue;
+            hbs[g].release(ctxs[g]);
+            if (comms[g]) pg_comm_destroy(comms[g]);
+            (void)hipSetDevice(ctxs[g]->device);
+            if (res[g]) (void)hipFree(res[g]);
+            if (all[g]) (void)hipFree(all[g]);
+            pg_ctx_destroy(ctxs[g]);
+        }
+    };
+    for (int g = 0; g < G && !rc; g++) {
+        rc = pg_ctx_create(g, &ctxs[g]);
+        if (!rc && hipMalloc(&res[g], (size_t)cols * 32) != hipSuccess) { set_error("pg_assoc_multi: GPU %d: out of memory", g); rc = PG_ENOMEM; }
+        if (!rc && hipMalloc(&all[g], (size_t)G * cols * 32) != hipSuccess) { set_error("pg_assoc_multi: GPU %d: out of memory", g); rc = PG_ENOMEM; }
+        if (!rc && hipMemsetAsync(res[g], 0, (size_t)cols * 32, ctxs[g]->stream) != hipSuccess) { set_error("pg_assoc_multi: memset failed"); rc = PG_EHIP; }
+    }
+    if (!rc) rc = pg_comm_init_all(G, ctxs.data(), comms.data());
+    if (rc) { teardown(); return rc; }
     std::vector<std::thread> th;
     for (int g = 0; g < G; g++) {
         th.emplace_back([&, g]() {
             const int64_t a = g * cols, b = std::min<int64_t>(p, a + cols);
-            if (a >= b) return;
-            pg_ctx *ctx = nullptr;
-            int rc = pg_ctx_create(g, &ctx);
-            if (!rc) {
-                rc = assoc_host_block(ctx, n, c, b - a, d, Wr, yr, X + a, p, grid, beta + a, se + a, tau + a, lambda + a, F + a,
-                                      pval ? pval + a : nullptr, nullptr);
-                if (rc) msgs[g] = pg_last_error();      // thread-local text: carry it to the caller's thread
-                pg_ctx_destroy(ctx);
-            } else msgs[g] = pg_last_error();
-            rcs[g] = rc;
+            int r = PG_OK;
+            if (a < b) r = assoc_host_block(ctxs[g], hbs[g], n, c, b - a, d, Wr, yr, X + a, p, grid, res[g], cols, pval != nullptr);
+            // every rank enters the collective, also after a local failure (its block then holds zeros), so no rank is left waiting
+            const int r2 = pg_comm_allgather_dev(comms[g], res[g], all[g], (size_t)cols * 32);
+            if (!r) r = r2;
+            if (!r && hipStreamSynchronize(ctxs[g]->stream) != hipSuccess) { set_error("stream failed: %s", hipGetErrorString(hipGetLastError())); r = PG_EHIP; }
+            if (r) msgs[g] = pg_last_error();      // thread-local text: carry it to the caller's thread
+            rcs[g] = r;
         });
     }
     for (auto &t : th) t.join();
-    for (int g = 0; g < G; g++)
-        if (rcs[g]) { set_error("pg_assoc_multi: GPU %d: %s", g, msgs[g].c_str()); return rcs[g]; }
-    return PG_OK;
+    for (int g = 0; g < G && !rc; g++)
+        if (rcs[g]) { set_error("pg_assoc_multi: GPU %d: %s", g, msgs[g].c_str()); rc = rcs[g]; }
+    if (!rc) {
+        (void)hipSetDevice(ctxs[0]->device);
+        for (int g = 0; g < G && !rc; g++) {
+            const int64_t a = g * cols, b = std::min<int64_t>(p, a + cols);
+            rc = copy_block_out(ctxs[0], all[0] + (size_t)g * cols * 32, cols, b - a, beta + a, se + a, tau + a, lambda + a, F + a,
+                                pval ? pval + a : nullptr);
+        }
+        if (!rc && hipStreamSynchronize(ctxs[0]->stream) != hipSuccess) { set_error("pg_assoc_multi: copy-out failed"); rc = PG_EHIP; }
+    }
+    teardown();
+    return rc;
 }

@@ -804,6 +804,63 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
 }
 
 // ------------------------------------------------------------------------------------------------
+// host side
+static size_t assoc_lds_bytes(int c, int n_vals)
+{
+    const int M = c + 2;
+    size_t per_wave = (size_t)NLAM * 2 * M * 8 + NLAM * sizeof(EvalOut) + 2 * NLAM * 4 + (size_t)n_vals * 4;
+    per_wave = (per_wave + 15) & ~(size_t)15;
+    return per_wave * WPB;
+}
+
+template <int C>
+static int launch_assoc(pg_ctx *ctx, AssocParams &pr)
+{
+    setup_tabs_kernel<C><<<NLAM, 64, (size_t)pr.n_vals * 4 + 16, ctx->stream>>>(pr);
+    PG_HIP(hipGetLastError());
+    const size_t lds = assoc_lds_bytes(C, pr.n_vals);
+    if (lds > 64 * 1024)
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&assoc_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long nblk = (pr.p + WPB - 1) / WPB;
+    assoc_kernel<C><<<dim3((unsigned)nblk), 64 * WPB, lds, ctx->stream>>>(pr);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+
+// The association kernel is instantiated per covariate count; the instantiations are split over two translation units
+// (assoc.hip: c = 1..15, assoc_hi.hip: c = 16..PG_MAX_COVARIATES) so that they compile in parallel.
+int launch_assoc_hi(pg_ctx *ctx, AssocParams &pr);
+#ifdef PG_ASSOC_HI
+int launch_assoc_hi(pg_ctx *ctx, AssocParams &pr)
+{
+    switch (pr.c) {
+#define PG_CASE(CC) case CC: return launch_assoc<CC>(ctx, pr);
+        PG_CASE(16) PG_CASE(17) PG_CASE(18) PG_CASE(19) PG_CASE(20) PG_CASE(21) PG_CASE(22) PG_CASE(23) PG_CASE(24) PG_CASE(25)
+        PG_CASE(26) PG_CASE(27) PG_CASE(28) PG_CASE(29) PG_CASE(30)
+#undef PG_CASE
+        default: return PG_ENOTSUP;
+    }
+}
+#else
+static int launch_assoc_any(pg_ctx *ctx, AssocParams &pr)
+{
+    switch (pr.c) {
+#define PG_CASE(CC) case CC: return launch_assoc<CC>(ctx, pr);
+#ifdef PG_ONLY_C
+        PG_CASE(PG_ONLY_C)
+#else
+        PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10)
+        PG_CASE(11) PG_CASE(12) PG_CASE(13) PG_CASE(14) PG_CASE(15)
+#endif
+#undef PG_CASE
+        default: return launch_assoc_hi(ctx, pr);
+    }
+}
+#endif
+
+#ifndef PG_ASSOC_HI
+// ------------------------------------------------------------------------------------------------
 // scipy.stats.f.sf(F, 1, dfd) (lmm.py:482): I_{w}(dfd/2, 1/2), w = dfd/(dfd+F) — same statements as
 // oracle orc_fdist_sf (continued fraction, modified Lentz).
 __device__ double betacf_dev(double a, double b, double x)
@@ -1051,30 +1108,6 @@ __global__ void reml_scalars_kernel(AssocParams pr, const float *a, float *out)
     out[2] = d2_f(pr, a[0], a[1], a[2], a[3], a[4], a[5]);
 }
 
-// ------------------------------------------------------------------------------------------------
-// host side
-static size_t assoc_lds_bytes(int c, int n_vals)
-{
-    const int M = c + 2;
-    size_t per_wave = (size_t)NLAM * 2 * M * 8 + NLAM * sizeof(EvalOut) + 2 * NLAM * 4 + (size_t)n_vals * 4;
-    per_wave = (per_wave + 15) & ~(size_t)15;
-    return per_wave * WPB;
-}
-
-template <int C>
-static int launch_assoc(pg_ctx *ctx, AssocParams &pr)
-{
-    setup_tabs_kernel<C><<<NLAM, 64, (size_t)pr.n_vals * 4 + 16, ctx->stream>>>(pr);
-    PG_HIP(hipGetLastError());
-    const size_t lds = assoc_lds_bytes(C, pr.n_vals);
-    if (lds > 64 * 1024)
-        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&assoc_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long long nblk = (pr.p + WPB - 1) / WPB;
-    assoc_kernel<C><<<dim3((unsigned)nblk), 64 * WPB, lds, ctx->stream>>>(pr);
-    PG_HIP(hipGetLastError());
-    return PG_OK;
-}
-
 }  // namespace pg
 
 using namespace pg;
@@ -1148,18 +1181,7 @@ extern "C" int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const floa
 
     build_fixed_kernel<<<(pr.npad + 255) / 256, 256, 0, ctx->stream>>>(pr.n, pr.npad, c, pr.rowf, d, Wr, yr, (float *)ctx->fixed);
     PG_HIP(hipGetLastError());
-    switch (c) {
-#define PG_CASE(CC) case CC: rc = launch_assoc<CC>(ctx, pr); break;
-#ifdef PG_ONLY_C
-        PG_CASE(PG_ONLY_C)
-#else
-        PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6)
-        PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10) PG_CASE(11) PG_CASE(12)
-        PG_CASE(13) PG_CASE(14) PG_CASE(15) PG_CASE(16) PG_CASE(17) PG_CASE(18) PG_CASE(19) PG_CASE(20)
-#endif
-#undef PG_CASE
-        default: rc = PG_ENOTSUP;
-    }
+    rc = launch_assoc_any(ctx, pr);
     if (rc) return rc;
     if (pval) return pg_fdist_sf_dev(ctx, p, F, (double)(n - c - 1), pval);
     return PG_OK;
@@ -1234,3 +1256,6 @@ extern "C" int pg_reml_scalars_dev(pg_ctx *ctx, int64_t n, int ctot, const float
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
+#else
+}  // namespace pg
+#endif  // PG_ASSOC_HI

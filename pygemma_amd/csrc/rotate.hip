@@ -29,6 +29,7 @@ struct RotParams {
     float *Xr;
     float scale;
     int tiles_m, tiles_n;
+    int lower;   // syrk mode (square output, X == U): only tiles on or below the diagonal are computed, the rest is mirrored
 };
 
 template <int VEC>
@@ -55,16 +56,24 @@ __global__ __launch_bounds__(256, 2) void rotate_kernel(RotParams rp)
     __shared__ float As[2][RBK][RBM];
     __shared__ float Bs[2][RBK][RBN];
     // ---- XCD-aware, grouped tile order
-    const int T = rp.tiles_m * rp.tiles_n;
+    const int T = rp.lower ? rp.tiles_m * (rp.tiles_m + 1) / 2 : rp.tiles_m * rp.tiles_n;
     const int b = blockIdx.x;
     const int q = T / 8, r = T % 8, xcd = b % 8;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-    const int per_group = RGROUP * rp.tiles_n;
-    const int grp = lid / per_group;
-    const int first_m = grp * RGROUP;
-    const int gsz = (rp.tiles_m - first_m) < RGROUP ? (rp.tiles_m - first_m) : RGROUP;
-    const int tm = first_m + (lid % per_group) % gsz;
-    const int tn = (lid % per_group) / gsz;
+    int tm, tn;
+    if (rp.lower) {      // lid -> (tm, tn), tn <= tm, row-major over the lower triangle of the tile grid
+        tm = (int)((sqrtf(8.0f * (float)lid + 1.0f) - 1.0f) * 0.5f);
+        while (tm * (tm + 1) / 2 > lid) tm--;
+        while ((tm + 1) * (tm + 2) / 2 <= lid) tm++;
+        tn = lid - tm * (tm + 1) / 2;
+    } else {
+        const int per_group = RGROUP * rp.tiles_n;
+        const int grp = lid / per_group;
+        const int first_m = grp * RGROUP;
+        const int gsz = (rp.tiles_m - first_m) < RGROUP ? (rp.tiles_m - first_m) : RGROUP;
+        tm = first_m + (lid % per_group) % gsz;
+        tn = (lid % per_group) / gsz;
+    }
     const long long m0 = (long long)tm * RBM, n0 = (long long)tn * RBN;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -132,7 +141,11 @@ __global__ __launch_bounds__(256, 2) void rotate_kernel(RotParams rp)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const long long row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (row < rp.p && col < rp.ldx) rp.Xr[row * rp.ldx + col] = rp.scale == 1.0f ? acc[i][j][e] : rp.scale * acc[i][j][e];
+                if (row < rp.p && col < rp.ldx) {
+                    const float v = rp.scale == 1.0f ? acc[i][j][e] : rp.scale * acc[i][j][e];
+                    rp.Xr[row * rp.ldx + col] = v;
+                    if (rp.lower && tn < tm && col < rp.ncol) rp.Xr[col * rp.ldx + row] = v;   // mirror of an off-diagonal tile
+                }
             }
         }
 }
@@ -142,13 +155,15 @@ __global__ __launch_bounds__(256, 2) void rotate_kernel(RotParams rp)
 using namespace pg;
 
 static int launch_tn(pg_ctx *ctx, long long kdim, long long ncol, long long p, const float *U, long long ldU, const float *X,
-                     long long ldX, float *out, long long ldx, float scale)
+                     long long ldX, float *out, long long ldx, float scale, bool lower = false)
 {
+    static_assert(RBM == RBN, "the syrk tile enumeration assumes square tiles");
     RotParams rp{};
     rp.kdim = kdim; rp.ncol = ncol; rp.p = p; rp.ldx = ldx; rp.ldU = ldU; rp.ldX = ldX; rp.U = U; rp.X = X; rp.Xr = out; rp.scale = scale;
     rp.tiles_m = (int)((p + RBM - 1) / RBM);
     rp.tiles_n = (int)((ncol + RBN - 1) / RBN);
-    const long long T = (long long)rp.tiles_m * rp.tiles_n;
+    rp.lower = lower ? 1 : 0;
+    const long long T = lower ? (long long)rp.tiles_m * (rp.tiles_m + 1) / 2 : (long long)rp.tiles_m * rp.tiles_n;
     PG_REQUIRE(T < (1LL << 31), "rotate: too many tiles; process SNPs in batches");
     const bool vec = (ldU % 4 == 0) && (ldX % 4 == 0) && (((uintptr_t)U | (uintptr_t)X) % 16 == 0);
     if (vec) rotate_kernel<4><<<dim3((unsigned)T), 256, 0, ctx->stream>>>(rp);
@@ -172,6 +187,79 @@ extern "C" int pg_kinship_dev(pg_ctx *ctx, int64_t n, int64_t p_k, const float *
 {
     PG_REQUIRE(ctx && Gt && K && n > 0 && p_k > 0 && ldg >= n, "pg_kinship_dev: bad arguments");
     PG_HIP(hipSetDevice(ctx->device));
-    // K[a][b] = (1/p_k) sum_g Gt[g][a] Gt[g][b]
-    return launch_tn(ctx, p_k, n, n, Gt, ldg, Gt, ldg, K, n, (float)(1.0 / (double)p_k));
+    // K[a][b] = (1/p_k) sum_g Gt[g][a] Gt[g][b]: a syrk — tiles on or below the diagonal on the MFMA pipe, the rest mirrored
+    // (bit-symmetric: K[a][b] and K[b][a] are the same fma chain over g of commuting products)
+    return launch_tn(ctx, p_k, n, n, Gt, ldg, Gt, ldg, K, n, (float)(1.0 / (double)p_k), true);
+}
+
+namespace pg {
+// per-column mean and 1/sd of G (n x p row-major), fp64: mu = mean, sd = sqrt(mean((x - mu)^2)) (numpy's np.std, ddof = 0),
+// sd == 0 -> 1 (experiments/animal_gwas/run_gwas.py:46-49).  blockDim (64, 4): 64 columns per block, rows strided over y.
+__global__ __launch_bounds__(256) void colstats_kernel(long long n, long long p, const float *G, long long ldG, double *mu, double *isd)
+{
+    __shared__ double red[4][64];
+    const long long g = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int ty = threadIdx.y;
+    double s = 0.0;
+    if (g < p) for (long long i = ty; i < n; i += 4) s += (double)G[i * ldG + g];
+    red[ty][threadIdx.x] = s;
+    __syncthreads();
+    const double m = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (double)n;
+    __syncthreads();
+    double v = 0.0;
+    if (g < p) for (long long i = ty; i < n; i += 4) { const double t = (double)G[i * ldG + g] - m; v = fma(t, t, v); }
+    red[ty][threadIdx.x] = v;
+    __syncthreads();
+    if (ty == 0 && g < p) {
+        const double var = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (double)n;
+        double sd = sqrt(var);
+        if (sd == 0.0) sd = 1.0;
+        mu[g] = m; isd[g] = 1.0 / sd;
+    }
+}
+// Zt[g][i] = float((G[i][g] - mu_g) / sd_g)  (SNP-major, row stride ldz, pad [n, ldz) zeroed); mu == nullptr: plain transpose
+__global__ __launch_bounds__(256) void standardize_t_kernel(long long n, long long p, const float *G, long long ldG, const double *mu,
+                                                            const double *isd, float *Zt, long long ldz)
+{
+    __shared__ float tile[32][33];
+    const long long g0 = (long long)blockIdx.x * 32, i0 = (long long)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const long long i = i0 + r, g = g0 + tx;
+        float v = 0.0f;
+        if (i < n && g < p) {
+            const double x = (double)G[i * ldG + g];
+            v = mu ? (float)((x - mu[g]) * isd[g]) : (float)x;
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long long g = g0 + r, i = i0 + tx;
+        if (g < p && i < ldz) Zt[g * ldz + i] = tile[tx][r];
+    }
+}
+}  // namespace pg
+
+// N3: K = Z Z' / p straight from the (n x p) genotype matrix as the reference's callers build it
+// (experiments/animal_gwas/run_gwas.py:46-56): column standardisation on the device (fp64 mean and population sd, sd == 0 -> 1),
+// then the lower-triangle syrk above.  K (n x n row-major float32, both triangles) can feed pg_syevd_dev directly.
+extern "C" int pg_kinship_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *G, int64_t ldG, int standardize, float *K)
+{
+    PG_REQUIRE(ctx && G && K && n > 0 && p > 0 && ldG >= p, "pg_kinship_geno_dev: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    const long long ldz = (n + 63) / 64 * 64;
+    const size_t off_stats = ((size_t)p * ldz * 4 + 255) & ~(size_t)255;
+    int rc = ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, off_stats + (size_t)p * 16);
+    if (rc) return rc;
+    float *Zt = (float *)ctx->scratch;
+    double *mu = (double *)((char *)ctx->scratch + off_stats), *isd = mu + p;
+    if (standardize) {
+        colstats_kernel<<<dim3((unsigned)((p + 63) / 64)), dim3(64, 4), 0, ctx->stream>>>(n, p, G, ldG, mu, isd);
+        PG_HIP(hipGetLastError());
+    }
+    dim3 grid((unsigned)((p + 31) / 32), (unsigned)((ldz + 31) / 32));
+    standardize_t_kernel<<<grid, 256, 0, ctx->stream>>>(n, p, G, ldG, standardize ? mu : nullptr, isd, Zt, ldz);
+    PG_HIP(hipGetLastError());
+    return pg_kinship_dev(ctx, n, p, Zt, ldz, K);
 }

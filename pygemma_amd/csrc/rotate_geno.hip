@@ -1,7 +1,7 @@
 // rotate_geno.hip — H2 on the fp16 MFMA pipe: X <- U'X for a block of SNP columns, 16x the fp32-MFMA rate.
 //
 // U is split once into two fp16 planes, S*U = H1 + H2 + e, S the power of two that puts S*max|U| in [2^14, 2^15) (keeps H2
-// out of the fp16 subnormals), round-to-nearest at both steps: |e| <= 2^-24 |S*U| — the size of float32's own rounding of U
+// out of the fp16 subnormals), round-to-nearest at both steps: |e| <= 2^-23 |S*U| worst case (2^-24 typical) — within one bit of float32's own rounding of U
 // (measured: the split adds 0.6x the error U already carries from that rounding, 1/20 of the fp32 accumulation error).
 //
 // (1) GENOTYPE columns — at most three equally spaced values (hard calls 0/1/2, raw or centred/standardised: what every
@@ -13,7 +13,7 @@
 //     callers do: experiments/benchmarks/benchmarks.py:243-244):  x_g = v0_g + dx_g * code_g + (o_g - v0_g) * ind_g  (code 0
 //     where ind = 1); the block takes a second, accumulating pass of the same GEMM on the 0/1 indicator plane.
 // (3) any other FINITE block (imputed dosages, arbitrary float X): X itself in two fp16 planes, s_g x = X1 + X2 + e (s_g a
-//     per-column power of two, |e| <= 2^-24 |s_g x|): pass 1 on X1, pass 2 accumulates X2.
+//     per-column power of two, |e| <= 2^-23 |s_g x|): pass 1 on X1, pass 2 accumulates X2.
 // (4) a block with a NaN/Inf is left to the fp32-MFMA kernel (pg_rotate_dev), whose propagation is the reference's sgemm's.
 // Error class of (1)-(3) = fp32 accumulation, the same as the fp32-MFMA kernel and the reference's sgemm (lmm/lmm.py:244).
 //

@@ -11,6 +11,12 @@ Same signature, same casts to float32 (lmm.py:115-128), same output DataFrame sc
 tau as float32; lambda, F_wald, p_wald as float64; SNPs as object when `snps` is given; lmm.py:403-409).
 `nproc` = number of GPUs to spread contiguous SNP blocks over, exactly like SampleIter's ceil(p/nproc)
 column blocks (lmm.py:427-434); results come back in block order = SNP order.
+
+Streaming (BASELINE configs 4-5): X never has to fit on a GPU.  Every GPU takes its block in batches; a batch is DMA'd
+from PINNED host memory (directly out of X when the caller allocated it with `pinned_empty`/`pin`, else through a pinned
+staging buffer filled by copy threads) on one stream while the previous batch computes on another, and its 32-byte
+result rows come back through a pinned buffer.  With several GPUs the eigenvectors travel once, GPU 0 -> all, as one
+RCCL broadcast over xGMI (pg_comm_*; no PyTorch).
 There is no CPU fallback: without the HIP library or a GPU this raises.
 """
 import ctypes as C
@@ -18,19 +24,22 @@ import json
 import os
 import threading
 import time
+import zlib
 
 import numpy as np
 import pandas as pd
 
 from . import _lib
+from ._lib import pin, pinned_empty     # noqa: F401  (re-exported: how a caller hands over pinned inputs)
 from .bed import PackedBed
 from .model import *          # noqa: F401,F403  (precompute_mat, calc_lambda_restricted, newton, the *_overload scalars)
 from . import model as _model
 
-__all__ = ["pygemma", "SampleIter"] + _model.__all__
+__all__ = ["pygemma", "SampleIter", "pinned_empty", "pin", "kinship"] + _model.__all__
 
 _BATCH_BYTES = 6 << 30   # device bytes for one SNP batch of one worker (raw block, rotated block, fp16 planes)
 _BATCH_SNPS = 32768      # SNPs per batch at most: the unit of copy/compute overlap and of checkpointing
+_STAGE_THREADS = 8       # host copy threads per worker for the pageable -> pinned leg
 
 
 class SampleIter:
@@ -66,26 +75,74 @@ def _rotate_small(ctx, L, n, dU, A):
 
 
 _COLS = ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald")
+_LRT_COLS = ("l_alt", "l_null", "D_lrt", "p_lrt")
 
 
 def _part_path(ckpt, s, e):
     return os.path.join(ckpt, f"part_{s:012d}_{e:012d}.npz")
 
 
-def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs, verbose, ckpt=None):
+def _crc(a):
+    return int(zlib.crc32(np.ascontiguousarray(a).view(np.uint8).reshape(-1)))
+
+
+def _block_fingerprint(X, s, e):
+    """Cheap identity of the raw SNP block [s, e): CRC-32 of 64 evenly spaced sample rows (of byte columns for packed
+    records).  Stored in every checkpoint part and compared before a part is restored, so that parts of a run on another
+    genotype matrix of the same shape are refused instead of being mixed into the result."""
+    if isinstance(X, PackedBed):
+        rec = X.data[s:e]
+        step = max(1, rec.shape[1] // 64)
+        return _crc(rec[:, ::step])
+    n = X.shape[0]
+    rows = np.unique(np.linspace(0, n - 1, min(n, 64)).astype(np.int64))
+    return _crc(X[rows, s:e])
+
+
+class _Staging:
+    """Pinned host buffers of one worker: the raw batch on its way in (unless X itself is pinned) and the result rows on
+    their way out."""
+
+    def __init__(self, ctx, L, in_bytes, out_bytes):
+        self.ctx, self.L = ctx, L
+        self.inp = self._alloc(in_bytes) if in_bytes else None
+        self.out = self._alloc(out_bytes)
+
+    def _alloc(self, nbytes):
+        p = C.c_void_p()
+        _lib.check(self.L.pg_host_alloc(self.ctx.handle, int(nbytes), C.byref(p)), "pg_host_alloc")
+        return p.value
+
+    def close(self):
+        for q in (self.inp, self.out):
+            if q:
+                self.L.pg_host_free(self.ctx.handle, q)
+        self.inp = self.out = None
+
+
+def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out, errs, verbose, ckpt=None, stats=None):
     """One GPU: SNP columns [a,b) of X through (rotate | transpose) -> assoc, in batches.  Two host threads per GPU, each with
-    its own stream and buffers, take batches from a shared list, so that the host->device copy of one batch overlaps the
-    kernels of the other.  With `ckpt` every finished batch is written to disk (and batches found there are not redone)."""
+    its own stream, device buffers and pinned staging, take batches from a shared list, so that the host->device DMA of one
+    batch overlaps the kernels of the other.  `dU`: GPU 0's resident eigenvectors (device 0) or None; with a communicator the
+    other GPUs receive them by RCCL broadcast.  With `ckpt` every finished batch is written to disk (and batches found there,
+    with a matching fingerprint of the raw block, are not redone)."""
     try:
         L = _lib.load()
-        ctx0 = _lib.Context(device)
+        ctx0 = comm.ctx if comm is not None else _lib.Context(device)
         try:
             ldx = (n + 63) // 64 * 64
             dd, dW, dy = ctx0.to_device(d), ctx0.to_device(Wr), ctx0.to_device(yr)
-            # U: already resident (GPU 0 keeps the eigensolver's output) or uploaded from the host copy
-            dU = (U_host if isinstance(U_host, _lib.DeviceBuffer) else ctx0.to_device(U_host)) if eigen else None
             dprep = None
-            if eigen:   # genotype fast path of the rotation (<= 3 equally spaced values per column), fp32 MFMA otherwise
+            if eigen:
+                # U: already resident (GPU 0 keeps the eigensolver's output); the other GPUs get it over xGMI
+                if comm is not None:
+                    t0 = time.time()
+                    if dU is None:
+                        dU = ctx0.alloc(n * n * 4)
+                    _lib.check(L.pg_comm_broadcast_dev(comm.handle, dU.ptr, n * n * 4, 0), "pg_comm_broadcast_dev")
+                    ctx0.sync()
+                    _log(verbose, f"GPU {device}: U ({n * n * 4 / 1e9:.2f} GB) broadcast over RCCL in {time.time() - t0:.3f} s")
+                # genotype fast path of the rotation (<= 3 equally spaced values per column), fp32 MFMA otherwise
                 dprep = ctx0.alloc(L.pg_geno_prep_bytes(n))
                 _lib.check(L.pg_geno_prep_dev(ctx0.handle, n, dU.ptr, n, dprep.ptr), "pg_geno_prep_dev")
             ctx0.sync()
@@ -98,12 +155,17 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
             ldX = (pb_max + 15) // 16 * 16
             bpr = (n + 3) // 4
             p = X.shape[1]
+            direct = (not packed) and _lib.is_pinned(X)        # X itself is page-locked: DMA straight out of it
+            nout = 32 + (32 if lrt else 0)                      # result bytes per SNP
             todo = []
             for s in range(a, b, pb_max):
                 e = min(s + pb_max, b)
                 if ckpt and os.path.exists(_part_path(ckpt, s, e)):
                     with np.load(_part_path(ckpt, s, e)) as z:
-                        for col in _COLS:
+                        if "fingerprint" not in z.files or int(z["fingerprint"]) != _block_fingerprint(X, s, e):
+                            raise ValueError(f"checkpoint part {_part_path(ckpt, s, e)} was computed from different genotypes "
+                                             f"(fingerprint of SNPs [{s},{e}) differs): refusing to mix runs")
+                        for col in _COLS + (_LRT_COLS if lrt else ()):
                             out[col][s:e] = z[col]
                     _log(verbose, f"GPU {device}: SNPs [{s},{e}) restored from {ckpt}")
                 else:
@@ -113,26 +175,40 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
             def worker():
                 try:
                     ctx = _lib.Context(device)
+                    stg = None
                     try:
-                        dX = ctx.alloc(pb_max * bpr if packed else n * ldX * esz)
+                        raw_bytes = pb_max * bpr if packed else n * ldX * esz
+                        dX = ctx.alloc(raw_bytes)
                         dXf = None       # float32 image of an 8-bit block, only if one does not qualify for the genotype path
                         dXr = ctx.alloc(pb_max * ldx * 4)
-                        dout, dF = ctx.alloc(pb_max * 16), ctx.alloc(pb_max * 16)
+                        dres = ctx.alloc(pb_max * nout)
                         dwork = ctx.alloc(L.pg_geno_work_bytes(n, pb_max)) if eigen else None
+                        stg = _Staging(ctx, L, 0 if direct else raw_bytes, pb_max * nout)
+                        hres = (C.c_char * (pb_max * nout)).from_address(stg.out)
                         while True:
                             with lock:
                                 if not todo or errs:
                                     return
                                 s, e = todo.pop(0)
                             pb = e - s
+                            t_in = time.time()
                             if packed:   # SNP records [s, e) of the .bed image: contiguous bytes; decode + impute + rotate on the device
-                                rec = np.ascontiguousarray(X.data[s:e])
-                                _lib.check(L.pg_memcpy_h2d(ctx.handle, dX.ptr, rec.ctypes.data, rec.nbytes), "pg_memcpy_h2d")
+                                rec = X.data[s:e]
+                                if rec.flags.c_contiguous:
+                                    _lib.check(L.pg_stage_rows(stg.inp, rec.nbytes, rec.ctypes.data, rec.nbytes, rec.nbytes, 1, 1), "pg_stage_rows")
+                                else:
+                                    C.memmove(stg.inp, np.ascontiguousarray(rec).ctypes.data, pb * bpr)
+                                _lib.check(L.pg_memcpy_h2d_async(ctx.handle, dX.ptr, stg.inp, pb * bpr), "pg_memcpy_h2d_async")
                                 _lib.check(L.pg_rotate_bed_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, bpr, int(X.count_A1), dXr.ptr, ldx,
                                                                dwork.ptr), "pg_rotate_bed_dev")
                             else:
-                                _lib.check(L.pg_memcpy2d_h2d(ctx.handle, dX.ptr, ldX * esz, X.ctypes.data + esz * s, p * esz, pb * esz, n),
-                                           "pg_memcpy2d_h2d")
+                                src = X.ctypes.data + esz * s
+                                if direct:
+                                    _lib.check(L.pg_memcpy2d_h2d_async(ctx.handle, dX.ptr, ldX * esz, src, p * esz, pb * esz, n),
+                                               "pg_memcpy2d_h2d_async")
+                                else:    # pageable X: copy threads gather the column window into pinned staging, then one dense DMA
+                                    _lib.check(L.pg_stage_rows(stg.inp, ldX * esz, src, p * esz, pb * esz, n, _STAGE_THREADS), "pg_stage_rows")
+                                    _lib.check(L.pg_memcpy_h2d_async(ctx.handle, dX.ptr, stg.inp, n * ldX * esz), "pg_memcpy_h2d_async")
                                 if x64:
                                     is_geno = C.c_int(0)
                                     _lib.check(L.pg_rotate_geno_f64_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx, dwork.ptr,
@@ -158,21 +234,43 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
                                         _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dX.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
                                 else:
                                     _lib.check(L.pg_transpose_dev(ctx.handle, n, pb, dX.ptr, ldX, dXr.ptr, ldx), "pg_transpose_dev")
-                            _lib.check(L.pg_assoc_dev(ctx.handle, n, c, pb, dd.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, int(grid),
-                                                      dout.ptr, dout.ptr + 4 * pb, dout.ptr + 8 * pb, dout.ptr + 12 * pb,
-                                                      dF.ptr, dF.ptr + 8 * pb, None), "pg_assoc_dev")
+                            # result block: [F | p | beta | se | tau | lambda] (+ [l_alt | l_null | D_lrt | p_lrt] f64 with lrt)
+                            r0 = dres.ptr
+                            if lrt:
+                                _lib.check(L.pg_assoc_lrt_dev(ctx.handle, n, c, pb, dd.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, int(grid),
+                                                              r0 + 16 * pb, r0 + 20 * pb, r0 + 24 * pb, r0 + 28 * pb, r0, r0 + 8 * pb,
+                                                              r0 + 32 * pb, r0 + 40 * pb, r0 + 48 * pb, r0 + 56 * pb), "pg_assoc_lrt_dev")
+                            else:
+                                _lib.check(L.pg_assoc_dev(ctx.handle, n, c, pb, dd.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, int(grid),
+                                                          r0 + 16 * pb, r0 + 20 * pb, r0 + 24 * pb, r0 + 28 * pb, r0, r0 + 8 * pb, None),
+                                           "pg_assoc_dev")
+                            _lib.check(L.pg_memcpy_d2h_async(ctx.handle, stg.out, r0, pb * nout), "pg_memcpy_d2h_async")
                             ctx.sync()
-                            res = dout.download((4, pb), np.float32)
-                            FP = dF.download((2, pb), np.float64)
+                            hb = np.frombuffer(hres, np.uint8, pb * nout)
+                            FP = hb[:16 * pb].view(np.float64).reshape(2, pb)
+                            res = hb[16 * pb:32 * pb].view(np.float32).reshape(4, pb)
                             out["beta"][s:e], out["se_beta"][s:e], out["tau"][s:e] = res[0], res[1], res[2]
                             out["lambda"][s:e] = res[3].astype(np.float64)
                             out["F_wald"][s:e], out["p_wald"][s:e] = FP[0], FP[1]
+                            if lrt:
+                                LR = hb[32 * pb:64 * pb].view(np.float64).reshape(4, pb)
+                                for k, col in enumerate(_LRT_COLS):
+                                    out[col][s:e] = LR[k]
+                            if stats is not None:
+                                with lock:
+                                    stats["batches"] += 1
+                                    stats["bytes_in"] += pb * bpr if packed else n * pb * esz
+                                    stats["batch_s"] += time.time() - t_in
                             if ckpt:
                                 tmp = _part_path(ckpt, s, e) + ".tmp.npz"
-                                np.savez(tmp, **{col: out[col][s:e] for col in _COLS})
+                                np.savez(tmp, fingerprint=np.int64(_block_fingerprint(X, s, e)),
+                                         **{col: out[col][s:e] for col in _COLS + (_LRT_COLS if lrt else ())})
                                 os.replace(tmp, _part_path(ckpt, s, e))
                             _log(verbose, f"GPU {device}: SNPs [{s},{e}) done")
                     finally:
+                        if stg is not None:
+                            ctx.sync()
+                            stg.close()
                         ctx.close()
                 except Exception as ex:  # surfaced by the caller; never swallowed
                     errs.append(ex)
@@ -183,21 +281,69 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, U_host, grid, eigen, out, errs,
             for th in workers:
                 th.join()
         finally:
-            ctx0.close()
+            if comm is None:
+                ctx0.close()
     except Exception as ex:  # surfaced by the caller; never swallowed
         errs.append(ex)
 
 
+class _Comm:
+    """One communicator of a pg_comm_init_all group + the context it is bound to."""
+
+    def __init__(self, handle, ctx):
+        self.handle, self.ctx = handle, ctx
+
+
+def _make_comms(L, ndev):
+    ctxs = [_lib.Context(g) for g in range(ndev)]
+    hs = (C.c_void_p * ndev)(*[c.handle for c in ctxs])
+    outs = (C.c_void_p * ndev)()
+    rc = L.pg_comm_init_all(ndev, hs, outs)
+    if rc:
+        msg = L.pg_last_error().decode()
+        for h in outs:
+            if h:
+                L.pg_comm_destroy(h)
+        for c in ctxs:
+            c.close()
+        raise _lib.PgError(f"pg_comm_init_all({ndev}) failed (code {rc}): {msg}")
+    return [_Comm(C.c_void_p(outs[g]), ctxs[g]) for g in range(ndev)]
+
+
+def kinship(G, standardize=True, device=0):
+    """K = Z Z' / p from the (n, p) genotype matrix G on the GPU (the step before the path in the reference's callers:
+    experiments/animal_gwas/run_gwas.py:46-56, tests/test_pygemma.py:184-192): columns centred and divided by their
+    standard deviation (population, ddof=0; sd == 0 -> 1) when `standardize`, then a lower-triangle syrk on the MFMA pipe.
+    Returns the (n, n) float32 matrix (both triangles)."""
+    L = _lib.load()
+    G = np.ascontiguousarray(G, np.float32)
+    n, p = G.shape
+    with _lib.Context(device) as ctx:
+        dG = ctx.to_device(G)
+        dK = ctx.alloc(n * n * 4)
+        _lib.check(L.pg_kinship_geno_dev(ctx.handle, n, p, dG.ptr, p, int(bool(standardize)), dK.ptr), "pg_kinship_geno_dev")
+        ctx.sync()
+        return dK.download((n, n), np.float32)
+
+
 def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=False, grid=False, eigen=True, nproc=1,
-            checkpoint=None):
+            checkpoint=None, lrt=False, eigenpairs=None, stats=None):
     """Per-SNP LMM association scan (GEMMA-style REML + Wald test) — signature of lmm/lmm.py:87.
 
     Y (n,1) phenotype; X (n,p) genotypes; W (n,c) covariates; K (n,n) relatedness matrix — or, with
     eigen=False, the (n,) vector of its eigenvalues with X, Y, W already rotated (lmm.py:164-167).
     Returns a pandas.DataFrame with columns beta, se_beta, tau, lambda, F_wald, p_wald[, SNPs].
-    Beyond the reference: X may be a `pygemma_amd.bed.PackedBed` (PLINK .bed kept packed; missing calls mean-imputed on
-    the device, as the reference's callers do on the host before calling); `checkpoint` names a directory that receives
-    every finished SNP batch, and a rerun with the same inputs picks up from what is there (the reference has no restart).
+    Beyond the reference (all keyword-only in spirit, defaults reproduce the reference):
+      * X may be a `pygemma_amd.bed.PackedBed` (PLINK .bed kept packed; missing calls mean-imputed on the device, as the
+        reference's callers do on the host before calling);
+      * `checkpoint` names a directory that receives every finished SNP batch; a rerun with the same inputs picks up from
+        what is there (the reference has no restart), a rerun with other inputs is refused;
+      * `lrt=True` appends l_alt, l_null, D_lrt, p_lrt — the likelihood-ratio columns the reference sketches and leaves
+        commented out (lmm.py:137-141, 277-300), from its own ML functions (lmm.py:22-84, pygemma_model.pyx:1542-1603);
+      * `eigenpairs=(eigenVals, U)`: a precomputed eigendecomposition of K (U column j = eigenvector j, as scipy.linalg.eigh
+        returns it) — K is ignored, U is streamed to the GPU(s) from host memory (pinned if made with `pinned_empty`) and the
+        rotation runs on the device (BASELINE config 5);
+      * `stats`: a dict that receives streaming counters (batches, bytes_in, seconds).
     """
     if de:
         # calculate_de is broken upstream (unpacks 4 of SampleIter's 5-tuple, lmm/lmm.py:499 vs :434)
@@ -206,7 +352,10 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     packed = isinstance(X, PackedBed)                         # extension: a PLINK .bed image instead of the float matrix
     if packed and not eigen:
         raise ValueError("a PackedBed holds raw genotypes: it cannot be used with eigen=False (pre-rotated inputs)")
-    Y, W, K = np.asarray(Y), np.asarray(W), np.asarray(K)
+    if eigenpairs is not None and not eigen:
+        raise ValueError("eigenpairs supplies U for the rotation: it goes with eigen=True")
+    Y, W = np.asarray(Y), np.asarray(W)
+    K = np.asarray(K) if K is not None else None
     if not packed:
         X = np.asarray(X)
     nproc = min(int(nproc), X.shape[1])                      # lmm.py:113
@@ -219,12 +368,13 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     x8 = (not packed) and eigen and X.dtype in (np.int8, np.uint8, np.float64)
     if not packed and not x8 and X.dtype != np.float32:
         X = X.astype(np.float32)                             # lmm.py:121-122
-    if Z is not None:
-        K = np.asarray(Z) @ K @ np.asarray(Z).T              # lmm.py:124-125
-    k64 = eigen and K.dtype == np.float64                    # rounded to float32 on the device instead (same values, no host copy)
-    if K.dtype != np.float32 and not k64:
-        K = K.astype(np.float32)                             # lmm.py:127-128
-    if not packed:
+    if eigenpairs is None:
+        if Z is not None:
+            K = np.asarray(Z) @ K @ np.asarray(Z).T          # lmm.py:124-125
+        k64 = eigen and K.dtype == np.float64                # rounded to float32 on the device instead (same values, no host copy)
+        if K.dtype != np.float32 and not k64:
+            K = K.astype(np.float32)                         # lmm.py:127-128
+    if not packed and not X.flags.c_contiguous:
         X = np.ascontiguousarray(X)
     n, p = X.shape
     c = W.shape[1]
@@ -233,35 +383,73 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     ngpu = _lib.device_count()
     if ngpu < 1:
         raise _lib.PgError("no MI355X visible: pygemma_amd has no CPU path")
-    ndev = max(1, min(nproc, ngpu))
+    blocks = list(SampleIter(p, max(1, min(nproc, ngpu))))   # one contiguous block per GPU, none empty
+    ndev = len(blocks)
 
     t0 = time.time()
-    U_host = None      # host copy of U: only needed to seed GPUs other than 0
     ectx = dU0 = None  # the eigensolver's context on GPU 0 and U resident there (reused by GPU 0's SNP loop)
     if eigen:
-        if K.shape != (n, n):
-            raise ValueError(f"K must be ({n},{n}) when eigen=True, got {K.shape}")
         ectx = _lib.Context(0)
         try:
-            if k64:
-                dK64 = ectx.to_device(np.ascontiguousarray(K))
-                dK = ectx.alloc(n * n * 4)
-                _lib.check(L.pg_cast_f64_f32_dev(ectx.handle, n, n, dK64.ptr, n, dK.ptr, n), "pg_cast_f64_f32_dev")   # lmm.py:127-128
-                ectx.sync()
-                dK64.free()
+            if eigenpairs is not None:
+                ev, Uh = eigenpairs
+                Uh = np.asarray(Uh)
+                if Uh.shape != (n, n):
+                    raise ValueError(f"eigenpairs: U must be ({n},{n}), got {Uh.shape}")
+                if Uh.dtype != np.float32 or not Uh.flags.c_contiguous:
+                    Uh = np.ascontiguousarray(Uh, np.float32)                       # lmm.py:154
+                eigenVals = np.maximum(0.0, np.asarray(ev)).astype(np.float32).reshape(-1)   # lmm.py:157-160
+                if eigenVals.shape[0] != n:
+                    raise ValueError(f"eigenpairs: {n} eigenvalues expected, got {eigenVals.shape}")
+                dU0 = ectx.alloc(n * n * 4)
+                if _lib.is_pinned(Uh):     # one DMA straight out of the caller's pinned array
+                    _lib.check(L.pg_memcpy_h2d_async(ectx.handle, dU0.ptr, Uh.ctypes.data, Uh.nbytes), "pg_memcpy_h2d_async")
+                    ectx.sync()
+                else:                      # pageable: row panels through a pinned double buffer, copy threads ahead of the DMA
+                    rows = max(1, min(n, (256 << 20) // (n * 4)))
+                    stg = _Staging(ectx, L, rows * n * 4, rows * n * 4)      # .inp / .out used as the two halves
+                    try:
+                        halves, k = (stg.inp, stg.out), 0
+                        evs = [C.c_void_p(), C.c_void_p()]
+                        for e_ in evs:
+                            _lib.check(L.pg_event_create(ectx.handle, C.byref(e_)), "pg_event_create")
+                        used = [False, False]
+                        for r0 in range(0, n, rows):
+                            r1 = min(n, r0 + rows)
+                            if used[k]:
+                                _lib.check(L.pg_event_sync(ectx.handle, evs[k]), "pg_event_sync")
+                            _lib.check(L.pg_stage_rows(halves[k], n * 4, Uh.ctypes.data + r0 * n * 4, n * 4, n * 4, r1 - r0, _STAGE_THREADS),
+                                       "pg_stage_rows")
+                            _lib.check(L.pg_memcpy_h2d_async(ectx.handle, dU0.ptr + r0 * n * 4, halves[k], (r1 - r0) * n * 4), "pg_memcpy_h2d_async")
+                            _lib.check(L.pg_event_record(ectx.handle, evs[k]), "pg_event_record")
+                            used[k] = True
+                            k ^= 1
+                        ectx.sync()
+                        for e_ in evs:
+                            L.pg_event_destroy(ectx.handle, e_)
+                    finally:
+                        stg.close()
+                _log(verbose, f"Eigenvectors uploaded ({n * n * 4 / 1e9:.2f} GB) - {time.time() - t0:.3f} s")
             else:
-                dK = ectx.to_device(K)
-            dev, dU0 = ectx.alloc(n * 4), ectx.alloc(n * n * 4)
-            _lib.check(L.pg_syevd_dev(ectx.handle, n, dK.ptr, dev.ptr, dU0.ptr, None, None), "pg_syevd_dev")
-            dK.free()
-            eigenVals = dev.download((n,), np.float32)       # ascending, clamped >= 0, float32 (lmm.py:152-160)
+                if K.shape != (n, n):
+                    raise ValueError(f"K must be ({n},{n}) when eigen=True, got {K.shape}")
+                if k64:
+                    dK64 = ectx.to_device(np.ascontiguousarray(K))
+                    dK = ectx.alloc(n * n * 4)
+                    _lib.check(L.pg_cast_f64_f32_dev(ectx.handle, n, n, dK64.ptr, n, dK.ptr, n), "pg_cast_f64_f32_dev")   # lmm.py:127-128
+                    ectx.sync()
+                    dK64.free()
+                else:
+                    dK = ectx.to_device(K)
+                dev, dU0 = ectx.alloc(n * 4), ectx.alloc(n * n * 4)
+                _lib.check(L.pg_syevd_dev(ectx.handle, n, dK.ptr, dev.ptr, dU0.ptr, None, None), "pg_syevd_dev")
+                dK.free()
+                eigenVals = dev.download((n,), np.float32)       # ascending, clamped >= 0, float32 (lmm.py:152-160)
+                _log(verbose, f"Eigendecomposition computed - {time.time() - t0:.3f} s")
             assert (eigenVals >= 0).all()                    # lmm.py:162
-            _log(verbose, f"Eigendecomposition computed - {time.time() - t0:.3f} s")
             t1 = time.time()
             YW = _rotate_small(ectx, L, n, dU0, np.concatenate([Y.reshape(n, -1)[:, :1], W], axis=1))
             Yr, Wr = YW[:, :1], np.ascontiguousarray(YW[:, 1:])
-            if ndev > 1:
-                U_host = dU0.download((n, n), np.float32)
             _log(verbose, f"Left multiplied Y, W by U.T - {time.time() - t1:.3f} s")
         except BaseException:
             ectx.close()
@@ -276,43 +464,64 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
         # lmm.py:253-256 (the reference tests the rotated arrays; a NaN anywhere in a raw column makes that
         # whole rotated column NaN, so testing the inputs raises in exactly the same cases)
         if (not packed and X.dtype.kind == 'f' and np.isnan(X).any()) or np.isnan(Yr).any() or np.isnan(Wr).any():
+            if ectx is not None:
+                ectx.close()
             raise ValueError("NaNs present in data")
 
     _log(verbose, f"Running {p} SNPs with {n} individuals on {ndev} GPU(s)...")
     out = {"beta": np.empty(p, np.float32), "se_beta": np.empty(p, np.float32), "tau": np.empty(p, np.float32),
            "lambda": np.empty(p, np.float64), "F_wald": np.empty(p, np.float64), "p_wald": np.empty(p, np.float64)}
+    if lrt:
+        for col in _LRT_COLS:
+            out[col] = np.empty(p, np.float64)
     errs, threads = [], []
+    if stats is not None:
+        stats.update({"batches": 0, "bytes_in": 0, "batch_s": 0.0, "pinned_input": bool((not packed) and _lib.is_pinned(X)), "gpus": ndev})
+    yr1 = np.ascontiguousarray(Yr.reshape(-1), np.float32)
     if checkpoint:
         os.makedirs(checkpoint, exist_ok=True)
-        key = {"n": int(n), "p": int(p), "c": int(c), "grid": bool(grid), "eigen": bool(eigen), "ndev": int(ndev),
+        # identity of the run: shapes, options, batch geometry and the SNP-independent inputs themselves (rotated y, W and the
+        # eigenvalues, byte for byte); the genotypes are fingerprinted per part (_block_fingerprint)
+        key = {"n": int(n), "p": int(p), "c": int(c), "grid": bool(grid), "eigen": bool(eigen), "ndev": int(ndev), "lrt": bool(lrt),
                "batch_snps": int(_BATCH_SNPS), "batch_bytes": int(_BATCH_BYTES),
-               "y_sum": float(np.asarray(Yr, np.float64).sum()), "d_sum": float(np.asarray(eigenVals, np.float64).sum())}
+               "y_crc": _crc(yr1), "w_crc": _crc(Wr), "d_crc": _crc(eigenVals)}
         mf = os.path.join(checkpoint, "manifest.json")
         if os.path.exists(mf):
             with open(mf) as f:
                 if json.load(f) != key:
+                    if ectx is not None:
+                        ectx.close()
                     raise ValueError(f"checkpoint directory {checkpoint} belongs to a different run (manifest mismatch)")
         else:
             with open(mf, "w") as f:
                 json.dump(key, f)
     t2 = time.time()
-    yr1 = np.ascontiguousarray(Yr.reshape(-1), np.float32)
+    comms = None
     try:
-        for dev_id, (a, b) in enumerate(SampleIter(p, ndev)):
+        if ndev > 1 and eigen:
+            comms = _make_comms(L, ndev)      # RCCL communicator over the GPUs of this process: U goes GPU 0 -> all over xGMI
+        for dev_id, (a, b) in enumerate(blocks):
             th = threading.Thread(target=_run_block, args=(dev_id, a, b, n, c, eigenVals, Wr, yr1, X,
-                                                           dU0 if (dev_id == 0 and dU0 is not None) else U_host, grid, eigen,
-                                                           out, errs, verbose, checkpoint))
+                                                           dU0 if dev_id == 0 else None, comms[dev_id] if comms else None,
+                                                           grid, eigen, lrt, out, errs, verbose, checkpoint, stats))
             th.start()
             threads.append(th)
         for th in threads:
             th.join()
     finally:
+        if comms:
+            for cm in comms:
+                L.pg_comm_destroy(cm.handle)
+                cm.ctx.close()
         if ectx is not None:
             ectx.close()
     if errs:
         raise errs[0]
+    if stats is not None:
+        stats["seconds"] = time.time() - t2
     _log(verbose, f"Finished testing {p} SNPs in {time.time() - t2:.3f} s")
-    results_df = pd.DataFrame(out, columns=["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"])   # lmm.py:403
+    cols = list(_COLS) + (list(_LRT_COLS) if lrt else [])
+    results_df = pd.DataFrame(out, columns=cols)                                                     # lmm.py:403
     if snps is not None:
         results_df["SNPs"] = snps                                                                    # lmm.py:408-409
     return results_df

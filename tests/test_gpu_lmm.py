@@ -88,13 +88,19 @@ def test_pygemma_from_packed_bed_matches_float_input(tmp_path):
     G = rng.binomial(2, rng.uniform(0.05, 0.5, p), size=(n, p)).astype(np.float64)
     G[rng.random((n, p)) < 0.01] = np.nan
     G[:, 5] = np.where(np.isnan(G[:, 5]), 0, G[:, 5])       # a SNP without missing calls
+    G[rng.random(n) < 0.6, 7] = np.nan                      # a SNP with most calls missing
+    G[:, 9] = np.nan                                        # all calls missing: no called genotype to average
     prefix = str(tmp_path / "toy")
     write_bed(prefix, G)
     bed = PackedBed.open(prefix + ".bed", count_A1=False)
     assert bed.shape == (n, p) and len(bed.snps) == p
-    Xf = bed.to_float()
-    mu = np.nanmean(G, axis=0)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)      # nanmean of the all-missing column
+        Xf = bed.to_float()
+        mu = np.nanmean(G, axis=0)
     np.testing.assert_array_equal(Xf, np.where(np.isnan(G), mu[None, :], G).astype(np.float32))
+    ok = np.ones(p, bool); ok[9] = False                    # the all-missing SNP is all-NaN on the float path, constant on the device
     GK = synth.genotypes(rng, n, 2 * n)
     K = (GK @ GK.T / (2 * n)).astype(np.float32)
     W = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, c - 1))], axis=1).astype(np.float32)
@@ -102,13 +108,32 @@ def test_pygemma_from_packed_bed_matches_float_input(tmp_path):
     a = lmm.pygemma(y, bed, W, K, snps=bed.snps)
     b = lmm.pygemma(y, Xf, W, K, snps=bed.snps)
     assert list(a.columns) == list(b.columns) and (a["SNPs"] == b["SNPs"]).all()
-    for col in ("beta", "se_beta", "tau", "lambda", "F_wald"):
-        np.testing.assert_allclose(a[col].to_numpy(), b[col].to_numpy(), rtol=2e-3, atol=1e-6, err_msg=col)
-    np.testing.assert_allclose(a["p_wald"].to_numpy(), b["p_wald"].to_numpy(), rtol=5e-3, atol=1e-12)
+    # both sides run the same fp16x2 GEMM on the same codes; they differ only in where the imputed mean is formed (device fp64 mean
+    # of the called genotypes vs numpy's nanmean rounded to float32): a few ulp of float32, nothing like a wrong divisor would give
+    for col in ("beta", "se_beta", "tau", "F_wald"):
+        np.testing.assert_allclose(a[col].to_numpy()[ok], b[col].to_numpy()[ok], rtol=2e-5, atol=1e-7, err_msg=col)
+    np.testing.assert_allclose(a["p_wald"].to_numpy()[ok], b["p_wald"].to_numpy()[ok], rtol=1e-4, atol=1e-12)
+    assert (np.abs(a["lambda"].to_numpy()[ok] / b["lambda"].to_numpy()[ok] - 1) <= 1e-3).mean() >= 0.99
+    # the rotated block itself, against an fp64 rotation of the host-decoded, mean-imputed matrix (1e-6 of the column norm)
+    from pygemma_amd import _lib
+    L = _lib.load()
+    with _lib.Context(0) as ctx:
+        ev, U32, ev64, U64 = __import__("pygemma_amd.ops", fromlist=["syevd"]).syevd(K, ctx=ctx, want64=True)
+        ldx = (n + 63) // 64 * 64
+        dU = ctx.to_device(U32); dprep = ctx.alloc(L.pg_geno_prep_bytes(n)); dwork = ctx.alloc(L.pg_geno_work_bytes(n, p))
+        _lib.check(L.pg_geno_prep_dev(ctx.handle, n, dU.ptr, n, dprep.ptr), "prep")
+        dB = ctx.to_device(np.ascontiguousarray(bed.data)); dXr = ctx.alloc(p * ldx * 4)
+        _lib.check(L.pg_rotate_bed_dev(ctx.handle, n, p, dprep.ptr, dB.ptr, bed.data.shape[1], 0, dXr.ptr, ldx, dwork.ptr), "rotate_bed")
+        ctx.sync()
+        Xr = dXr.download((p, ldx), np.float32)[:, :n]
+    X64 = np.where(np.isnan(G), mu[None, :], G)
+    ref = (U32.astype(np.float64).T @ X64[:, ok]).T
+    err = np.abs(Xr[ok] - ref).max(axis=1) / np.linalg.norm(X64[:, ok], axis=0)
+    assert err.max() <= 1e-6, err.max()
     # A1 dosage = 2 - A2 dosage: beta flips sign, the test statistic does not change
     a1 = lmm.pygemma(y, PackedBed.open(prefix, count_A1=True), W, K)
-    np.testing.assert_allclose(a1["beta"].to_numpy(), -a["beta"].to_numpy(), rtol=2e-3, atol=1e-6)
-    np.testing.assert_allclose(a1["F_wald"].to_numpy(), a["F_wald"].to_numpy(), rtol=5e-3, atol=1e-6)
+    np.testing.assert_allclose(a1["beta"].to_numpy()[ok], -a["beta"].to_numpy()[ok], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(a1["F_wald"].to_numpy()[ok], a["F_wald"].to_numpy()[ok], rtol=5e-4, atol=1e-6)
 
 
 def test_checkpoint_restart(tmp_path, monkeypatch):
@@ -137,6 +162,12 @@ def test_checkpoint_restart(tmp_path, monkeypatch):
     assert (b["beta"].to_numpy()[512:] == ref["beta"].to_numpy()[512:]).all()
     with pytest.raises(ValueError):
         lmm.pygemma(Y, X[:, :700], W, d, eigen=False, checkpoint=ck)
+    # another genotype matrix of the same shape, or other covariates with the same c, must be refused, not mixed in
+    X2 = X.copy(); X2[:, 100] += 1.0
+    with pytest.raises(ValueError, match="different genotypes"):
+        lmm.pygemma(Y, X2, W, d, eigen=False, checkpoint=ck)
+    with pytest.raises(ValueError, match="manifest"):
+        lmm.pygemma(Y, X, W * np.float32(1.5), d, eigen=False, checkpoint=ck)
 
 
 @pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.float64])

@@ -1,0 +1,191 @@
+"""GPU tests of the streaming / multi-GPU legs (BASELINE configs 4-5):
+pinned-memory batch streaming in lmm.pygemma, the RCCL communicator behind the C ABI, n = 50 000 end to end."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a.view(np.uint64)
+
+
+COLS = ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald")
+
+
+def test_pinned_helpers():
+    from pygemma_amd import _lib
+    a = _lib.pinned_empty((300, 70), np.float32)
+    assert a.shape == (300, 70) and a.dtype == np.float32 and a.flags.c_contiguous and a.flags.writeable
+    a[:] = 3.0
+    assert _lib.is_pinned(a) and _lib.is_pinned(a[10:20, 5:9])
+    b = np.zeros((64, 64), np.float32)
+    assert not _lib.is_pinned(b)
+    h = _lib.pin(b)
+    assert _lib.is_pinned(b)
+    h.close()
+    assert not _lib.is_pinned(b)
+    del a   # releases the hipHostMalloc'd block through the finalizer
+
+
+@pytest.mark.parametrize("grid", [False, True])
+def test_streamed_batches_pinned_equals_pageable_equals_oracle(grid, monkeypatch):
+    """>= 4 streamed batches per GPU, X once in pinned memory (direct 2-D DMA) and once pageable (copy threads -> pinned
+    staging): identical frames, bit-identical to the oracle at the eigen-basis boundary."""
+    from oracle import oracle as O
+    from pygemma_amd import lmm, synth
+    monkeypatch.setattr(lmm, "_BATCH_SNPS", 512)
+    rp = synth.rotated_panel(384, 2300, 3, seed=12)        # ragged: 4 x 512 + 252
+    Xp = lmm.pinned_empty(rp["X"].shape, np.float32)
+    Xp[:] = rp["X"]
+    st_a, st_b = {}, {}
+    a = lmm.pygemma(rp["Y"], Xp, rp["W"], rp["d"], eigen=False, grid=grid, stats=st_a)
+    b = lmm.pygemma(rp["Y"], rp["X"], rp["W"], rp["d"], eigen=False, grid=grid, stats=st_b)
+    assert st_a["pinned_input"] and not st_b["pinned_input"] and st_a["batches"] == 5 and st_b["batches"] == 5
+    orc = O.calculate(rp["d"], rp["Y"], rp["W"], rp["X"], grid=grid, order=1, nthreads=8)
+    for col in COLS[:5]:
+        assert (bits(a[col].to_numpy()) == bits(b[col].to_numpy())).all(), col
+        assert (bits(a[col].to_numpy()) == bits(orc[col].astype(a[col].dtype))).all(), col
+    np.testing.assert_allclose(a["p_wald"].to_numpy(), orc["p_wald"], rtol=1e-9)
+
+
+def test_config5_n50000_eigen_false_grid_streamed_from_pinned(monkeypatch):
+    """BASELINE configs[4] shape on one GPU: n = 50 000, grid path, pre-rotated X streamed from pinned host memory in 4
+    batches (the reference's eigen=False caller: experiments/large_gwas/run_pygemma.py:33-65); a sample of SNPs is compared
+    bit-for-bit with the oracle, and every row must be finite."""
+    from oracle import oracle as O
+    from pygemma_amd import lmm, synth
+    n, p, c = 50000, 8192, 5
+    monkeypatch.setattr(lmm, "_BATCH_SNPS", 2048)
+    rp = synth.fast_rotated_panel(n, 64, c, seed=50)        # d, y, W and 64 structured columns
+    rng = np.random.default_rng(51)
+    X = lmm.pinned_empty((n, p), np.float32)                # 1.6 GB page-locked
+    for s in range(0, p, 1024):
+        X[:, s:s + 1024] = rng.standard_normal((n, 1024), dtype=np.float32)
+    X[:, :64] = rp["X"]
+    st = {}
+    df = lmm.pygemma(rp["Y"], X, rp["W"], rp["d"], eigen=False, grid=True, stats=st)
+    assert st["batches"] == 4 and st["pinned_input"] and st["bytes_in"] == n * p * 4
+    assert len(df) == p and np.isfinite(df["beta"].to_numpy()).all() and (df["p_wald"].to_numpy() <= 1).all()
+    idx = np.concatenate([np.arange(8), [2047, 2048, 4095, 4096, 6143, 6144, p - 2, p - 1], rng.integers(64, p, 8)])
+    orc = O.calculate(rp["d"], rp["Y"], rp["W"], np.ascontiguousarray(X[:, idx]), grid=True, order=1, nthreads=16)
+    for col in COLS[:5]:
+        assert (bits(df[col].to_numpy()[idx]) == bits(orc[col].astype(df[col].dtype))).all(), col
+    np.testing.assert_allclose(df["p_wald"].to_numpy()[idx], orc["p_wald"], rtol=1e-9)
+
+
+def test_config5_n40000_rotation_from_host_eigenpairs(monkeypatch):
+    """BASELINE configs[4]'s rotation leg: precomputed eigenpairs (U = 6.4 GB float32 at n = 40 000) streamed from pinned host
+    memory, genotype rotation on the fp16 MFMA pipe at that size, association on top.  Checked: sampled rotated entries against
+    an fp64 dot product (error bound of tests/test_gpu_rotate.py), and the whole frame against the oracle fed with fp64-rotated
+    columns (Tier C bar: the fp32-accumulation error class of the reference's own sgemm)."""
+    from oracle import oracle as O
+    from pygemma_amd import _lib, lmm
+    n, p, c = 40000, 1536, 2
+    monkeypatch.setattr(lmm, "_BATCH_SNPS", 512)
+    rng = np.random.default_rng(40)
+    U = lmm.pinned_empty((n, n), np.float32)
+    for r in range(0, n, 2000):                               # entries ~ N(0, 1/n): the scale of an orthogonal matrix
+        U[r:r + 2000] = rng.standard_normal((2000, n), dtype=np.float32) * np.float32(1.0 / np.sqrt(n))
+    d = np.sort(rng.gamma(2.0, 0.5, n)).astype(np.float32)
+    maf = rng.uniform(0.05, 0.5, p)
+    X = rng.binomial(2, maf, size=(n, p)).astype(np.float32)
+    W = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, c - 1))], axis=1).astype(np.float32)
+    Y = (0.05 * X[:, :1] + rng.standard_normal((n, 1))).astype(np.float32)
+    # (a) the rotation alone, through the C ABI, on the first 512 SNPs
+    L = _lib.load()
+    with _lib.Context(0) as ctx:
+        ldx = (n + 63) // 64 * 64
+        dU = ctx.alloc(n * n * 4)
+        _lib.check(L.pg_memcpy_h2d_async(ctx.handle, dU.ptr, U.ctypes.data, U.nbytes), "h2d")
+        dprep = ctx.alloc(L.pg_geno_prep_bytes(n)); dwork = ctx.alloc(L.pg_geno_work_bytes(n, 512))
+        _lib.check(L.pg_geno_prep_dev(ctx.handle, n, dU.ptr, n, dprep.ptr), "prep")
+        dX = ctx.to_device(np.ascontiguousarray(X[:, :512])); dXr = ctx.alloc(512 * ldx * 4)
+        flag = C.c_int(0)
+        _lib.check(L.pg_rotate_geno_dev(ctx.handle, n, 512, dprep.ptr, dX.ptr, 512, dXr.ptr, ldx, dwork.ptr, C.byref(flag)), "rotate_geno")
+        ctx.sync()
+        assert flag.value == 1
+        Xr = dXr.download((512, ldx), np.float32)
+    gs, ks = rng.integers(0, 512, 48), rng.integers(0, n, 48)
+    for g, k in zip(gs, ks):
+        uk, xg = U[:, k].astype(np.float64), X[:, g].astype(np.float64)
+        ref = float(uk @ xg)
+        bound = 4 * 2.0 ** -24 * np.sqrt(n) * float(np.abs(uk) @ np.abs(xg)) / np.sqrt(n) + 1e-6
+        assert abs(float(Xr[g, k]) - ref) <= max(bound, 2e-5 * np.sqrt(float((uk * uk) @ (xg * xg)))), (g, k, Xr[g, k], ref)
+    assert (Xr[:, n:] == 0).all()
+    # (b) the pipeline from host eigenpairs
+    st = {}
+    df = lmm.pygemma(Y, X, W, None, eigenpairs=(d, U), stats=st)
+    assert st["batches"] == 3 and np.isfinite(df["beta"].to_numpy()).all()
+    idx = np.array([0, 1, 511, 512, 1023, 1024, p - 1])
+    U64 = U.astype(np.float64)
+    rot = lambda A: (U64.T @ A.astype(np.float64)).astype(np.float32)
+    truth = O.calculate(d, rot(Y), rot(W), rot(X[:, idx]), grid=False, order=0, nthreads=16)
+    # (lambda itself is not compared: with this near-null phenotype most SNPs sit at the 1e-5 boundary where logL is flat)
+    for col, tol in (("beta", 2e-3), ("se_beta", 1e-4)):
+        np.testing.assert_allclose(df[col].to_numpy()[idx].astype(np.float64), truth[col].astype(np.float64), rtol=tol, atol=1e-7, err_msg=col)
+    np.testing.assert_allclose(np.log(df["p_wald"].to_numpy()[idx]), np.log(truth["p_wald"]), rtol=5e-3, atol=5e-3)
+
+
+def test_comm_single_rank_collectives():
+    """The RCCL communicator behind the C ABI (librccl dlopen'ed, no torch): id + init_rank with one rank, then every
+    collective the path uses.  (A 1-GPU box can only form a 1-rank communicator; the 2-rank case is below.)"""
+    from pygemma_amd import _lib
+    L = _lib.load()
+    with _lib.Context(0) as ctx:
+        uid = (C.c_char * 128)()
+        _lib.check(L.pg_comm_unique_id(uid), "pg_comm_unique_id")
+        comm = C.c_void_p()
+        _lib.check(L.pg_comm_init_rank(ctx.handle, 1, 0, uid, C.byref(comm)), "pg_comm_init_rank")
+        assert L.pg_comm_size(comm) == 1 and L.pg_comm_rank(comm) == 0
+        a = np.arange(1000, dtype=np.float64)
+        da, db = ctx.to_device(a), ctx.alloc(a.nbytes)
+        _lib.check(L.pg_comm_broadcast_dev(comm, da.ptr, a.nbytes, 0), "broadcast")
+        _lib.check(L.pg_comm_allgather_dev(comm, da.ptr, db.ptr, a.nbytes), "allgather")
+        _lib.check(L.pg_comm_allreduce_f64_dev(comm, da.ptr, a.size, 1), "allreduce max")
+        _lib.check(L.pg_comm_barrier(comm), "barrier")
+        assert (db.download((1000,), np.float64) == a).all() and (da.download((1000,), np.float64) == a).all()
+        _lib.check(L.pg_comm_destroy(comm), "destroy")
+
+
+def test_pg_assoc_multi_gathers_rows_over_rccl():
+    """pg_assoc_multi: SampleIter blocks, one RCCL all-gather of the padded 32-byte row blocks, GPU 0's copy out — equal to the
+    single-context pg_assoc bit for bit (with one GPU the communicator has one rank; with more, the blocks really travel)."""
+    from pygemma_amd import _lib, synth
+    L = _lib.load()
+    rp = synth.rotated_panel(300, 37, 2, seed=3)
+    n, p = rp["X"].shape
+    c = rp["W"].shape[1]
+    X = np.ascontiguousarray(rp["X"]); y = np.ascontiguousarray(rp["Y"].reshape(-1))
+
+    def outs():
+        return [np.empty(p, np.float32) for _ in range(4)] + [np.empty(p, np.float64) for _ in range(2)]
+    o1, o2 = outs(), outs()
+    with _lib.Context(0) as ctx:
+        _lib.check(L.pg_assoc(ctx.handle, n, c, p, rp["d"].ctypes.data, rp["W"].ctypes.data, y.ctypes.data, X.ctypes.data, 0,
+                              *[o.ctypes.data for o in o1], None), "pg_assoc")
+    ng = max(1, min(_lib.device_count(), 4))
+    _lib.check(L.pg_assoc_multi(ng, n, c, p, rp["d"].ctypes.data, rp["W"].ctypes.data, y.ctypes.data, X.ctypes.data, 0,
+                                *[o.ctypes.data for o in o2]), "pg_assoc_multi")
+    for a, b in zip(o1, o2):
+        assert (bits(a) == bits(b)).all()
+
+
+def test_two_gpus_equal_one_gpu_bit_for_bit():
+    """nproc=2 (two SampleIter blocks, U broadcast GPU 0 -> 1 over RCCL) == nproc=1, all columns, eigen=True and eigen=False."""
+    from pygemma_amd import _lib, lmm, synth
+    if _lib.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the round's GPU box has one)")
+    raw = synth.panel(512, 1001, 3, seed=9)
+    a = lmm.pygemma(raw["Y"], raw["X"], raw["W"], raw["K"], nproc=1)
+    b = lmm.pygemma(raw["Y"], raw["X"], raw["W"], raw["K"], nproc=2)
+    for col in COLS:
+        assert (bits(a[col].to_numpy()) == bits(b[col].to_numpy())).all(), col
+    rp = synth.rotated_panel(300, 333, 2, seed=2)
+    a = lmm.pygemma(rp["Y"], rp["X"], rp["W"], rp["d"], eigen=False, nproc=1)
+    b = lmm.pygemma(rp["Y"], rp["X"], rp["W"], rp["d"], eigen=False, nproc=2)
+    for col in COLS:
+        assert (bits(a[col].to_numpy()) == bits(b[col].to_numpy())).all(), col
