@@ -125,6 +125,19 @@ int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const
                  const float *Xr, int64_t ldx, int grid, float *beta, float *se, float *tau, float *lambda,
                  double *F, double *pval, unsigned long long *stats_dev);
 
+/* ---- N2: the same operator plus the likelihood-ratio test the reference sketches and leaves commented out
+ * ("Fix these calculations later", lmm/lmm.py:137-141, 277-300), built from its own ML functions: lambda_alt =
+ * calc_lambda(eigenVals, Y, [W, x]) (lmm/lmm.py:22-84: decade scan of dlogL/dlambda, brentq(rtol=0.1) + scipy newton),
+ * l_alt = likelihood_lambda(lambda_alt, ...) (pygemma_model.pyx:1542-1562; derivatives :1567-1603), l_null the same for the
+ * covariates alone, D_lrt = 2 (l_alt - l_null) on float32 scalars, p_lrt = chi2(1).sf(D_lrt).  The first six outputs are
+ * bit-identical to pg_assoc_dev's.  l_alt, l_null (the same value in every row), D_lrt: float32 values widened to float64
+ * (like the frame's lambda column); p_lrt float64.  The reference evaluates the quadratic forms of its ML functions with
+ * float32 NumPy helpers (pyx:2045-2180); here they come from the same float64 sweeps as the REML path, so agreement with the
+ * reference is at its float32 noise (l within 2 ulp, D within 2.5e-4: tests/golden/lrt_panels.npz), not bit-for-bit. */
+int pg_assoc_lrt_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
+                     const float *Xr, int64_t ldx, int grid, float *beta, float *se, float *tau, float *lambda,
+                     double *F, double *pval, double *l_alt, double *l_null, double *D_lrt, double *p_lrt);
+
 /* host-pointer convenience: X in the REFERENCE layout (n x p row-major, already rotated), as
  * calculate() receives it; transposed to SNP-major on the device. */
 int pg_assoc(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,

@@ -60,6 +60,21 @@ def lib():
                                  C.POINTER(C.c_int)]
         L.orc_wrapper_d1.restype = C.c_float
         L.orc_wrapper_d1.argtypes = [C.c_float, f32p, f32p, f32p, C.c_long, C.c_int, C.c_int]
+        L.orc_ml_logl.restype = C.c_float
+        L.orc_ml_logl.argtypes = [C.c_int, C.c_float, C.c_float]
+        L.orc_ml_d1.restype = C.c_float
+        L.orc_ml_d1.argtypes = [C.c_float, C.c_int, C.c_float, C.c_float, C.c_float]
+        L.orc_ml_d2.restype = C.c_float
+        L.orc_ml_d2.argtypes = [C.c_float, C.c_int] + [C.c_float] * 5
+        L.orc_calc_lambda_ml.restype = C.c_float
+        L.orc_calc_lambda_ml.argtypes = [f32p, f32p, f32p, C.c_long, C.c_int, C.c_int, f32p]
+        L.orc_ml_functions.restype = None
+        L.orc_ml_functions.argtypes = [C.c_float, f32p, f32p, f32p, C.c_long, C.c_int, C.c_int, f32p]
+        L.orc_calculate_lrt.restype = C.c_int
+        L.orc_calculate_lrt.argtypes = [f32p, f32p, f32p, f32p, C.c_long, C.c_long, C.c_long, C.c_int, C.c_long, C.c_int, C.c_int,
+                                        f32p, f32p, f32p, f32p, f32p, f64p]
+        L.orc_chi2_sf1.restype = C.c_double
+        L.orc_chi2_sf1.argtypes = [C.c_double]
         L.orc_max_threads.restype = C.c_int
         L.orc_brentq.restype = C.c_double
         L.orc_rotate.restype = None
@@ -135,3 +150,38 @@ def rotate(U, X, ldx=None):
     out = np.empty((p, ldx), np.float32)
     L.orc_rotate(U, X, n, p, out, ldx)
     return out
+
+
+def calc_lambda_ml(d, y, Wx, order=0):
+    """Mirror of calc_lambda(eigenVals, Y, W) (lmm/lmm.py:22-84): (lambda_ML, likelihood_lambda at it)."""
+    L = lib()
+    d, y, Wx = _c(d), _c(np.asarray(y).reshape(-1)), _c(Wx)
+    n, ctot = Wx.shape
+    ll = np.zeros(1, np.float32)
+    lam = L.orc_calc_lambda_ml(d, y, Wx, n, ctot, int(order), ll)
+    return float(lam), float(ll[0])
+
+
+def ml_functions(lam, d, y, Wx, order=0):
+    """likelihood_lambda, likelihood_derivative1_lambda, likelihood_derivative2_lambda (pyx:1542-1603) at lam."""
+    L = lib()
+    d, y, Wx = _c(d), _c(np.asarray(y).reshape(-1)), _c(Wx)
+    n, ctot = Wx.shape
+    out = np.zeros(3, np.float32)
+    L.orc_ml_functions(np.float32(lam), d, y, Wx, n, ctot, int(order), out)
+    return out
+
+
+def calculate_lrt(d, y, W, X, order=0, nthreads=1):
+    """The LRT columns the reference sketches (lmm/lmm.py:277-300): per SNP lambda_alt = calc_lambda(d, Y, [W, x]),
+    l_alt = likelihood at it; l_null the same for W alone; D_lrt = 2 (l_alt - l_null); p_lrt = chi2(1).sf(D_lrt)."""
+    L = lib()
+    d, y, W, X = _c(d), _c(np.asarray(y).reshape(-1)), _c(W), _c(X)
+    n, c = W.shape
+    p = X.shape[1]
+    la, lam, D = (np.empty(p, np.float32) for _ in range(3))
+    ln, lam0 = np.zeros(1, np.float32), np.zeros(1, np.float32)
+    pl = np.empty(p, np.float64)
+    rc = L.orc_calculate_lrt(d, y, W, X, p, 1, n, c, p, int(order), int(nthreads), la, lam, ln, lam0, D, pl)
+    assert rc == 0
+    return {"l_alt": la, "lambda_alt": lam, "l_null": float(ln[0]), "lambda_null": float(lam0[0]), "D_lrt": D, "p_lrt": pl}

@@ -435,6 +435,7 @@ typedef struct {
 typedef struct {
     float yPy, yPPy, yPPPy, trP, trPP, ld; /* level ctot */
     float Pxx_c, Pyx_c;                    /* level ctot-1: wjt_Pi_wk[c,c,c], wjt_Pi_wk[c+1,c,c] */
+    float sh, shh;                         /* level 0: sum h, sum h^2 (h = 1/(lam d + 1)) — the un-projected traces the ML functions use */
 } eval_t;
 
 typedef struct { eval_t *e; int m; } evalcb_t;
@@ -456,6 +457,7 @@ static void snp_eval(snp_ctx_t *s, float lam, int full, eval_t *e)
     evalcb_t cb = { e, m };
     sweeps(&g, m, full, s->order, &o, eval_cb, &cb);
     e->trP = (float)o.trP[m - 1]; e->trPP = (float)o.trPP[m - 1]; e->ld = o.ld;
+    e->sh = (float)o.trP[0]; e->shh = (float)o.trPP[0];
     if (full) s->n_eval_full++; else s->n_eval_fast++;
 }
 /* pyx:1631-1649 wrapper_likelihood_derivative1_restricted_lambda */
@@ -727,6 +729,173 @@ float orc_wrapper_d1(float lam, const float *d, const float *y, const float *Wx,
     free(buf);
     return r;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* N2: the ML (non-restricted) likelihood and the LRT the reference sketches.  */
+/*   likelihood_lambda pyx:1542-1562, likelihood_derivative1_lambda pyx:1567-1581,         */
+/*   likelihood_derivative2_lambda pyx:1586-1603, calc_lambda lmm/lmm.py:22-84,            */
+/*   D_lrt = 2 (l_alt - l_null), p_lrt = 1 - chi2.cdf(D_lrt, 1)  (lmm/lmm.py:277-300,      */
+/*   commented out upstream: "Fix these calculations later").                             */
+/* The reference evaluates the quadratic forms y'P y, y'PP y, y'PPP y of these functions    */
+/* through compute_at_Pi_b & co (pyx:2045-2180: float32 NumPy products + np.linalg.inv in  */
+/* float32), whose rounding no independent implementation reproduces.  The restatement     */
+/* evaluates the SAME forms with precompute_mat's sweeps (identical algebra, float64       */
+/* Grams: more exact), takes sum h and sum h^2 from the level-0 traces, and then follows    */
+/* the reference's statements with the C widths of the generated code.  Parity of this      */
+/* path is therefore a TOLERANCE (the reference's own float32 noise), pinned by fixtures    */
+/* made by calling the real reference's functions (tests/golden/lrt_*.npz).                */
+/* l_alt: the sketch's likelihood(lambda_alt, tau = n/y'Py, beta_GLS, ...) (pyx:1736-1754)  */
+/* equals likelihood_lambda(lambda_alt) analytically (the residual form is y'Py, so the     */
+/* last term is -n/2); the restatement uses likelihood_lambda for both l_alt and l_null.    */
+/* ------------------------------------------------------------------------------------ */
+float orc_ml_logl(int n, float yPy, float ldH)
+{
+    const long h = (long)n / 2;                                              /* (n/2): C integer division (cdivision) */
+    float r = (float)((double)h * log((double)n / (2.0 * M_PI)));            /* pyx:1552 */
+    r = r - (float)h;                                                        /* pyx:1554  float - long */
+    r = r - 0.5f * ldH;                                                      /* pyx:1556  (float32 scalars) */
+    float t = (MIN_VAL > yPy) ? MIN_VAL : yPy;
+    r = (float)((double)r - (double)h * log((double)t));                     /* pyx:1558 */
+    return r;
+}
+float orc_ml_d1(float lam, int n, float yPy, float yPPy, float sh)
+{
+    float r = -0.5f * (((float)n - sh) / lam);                               /* pyx:1574  (float32 scalars) */
+    float num = (MIN_VAL > yPPy) ? MIN_VAL : yPPy, den = (MIN_VAL > yPy) ? MIN_VAL : yPy;   /* pyx:1576-1577 */
+    r = (float)((double)r + ((double)((long)n / 2) * (1.0 - (double)(num / den))) / (double)lam);   /* pyx:1579 */
+    return r;
+}
+float orc_ml_d2(float lam, int n, float yPy, float yPPy, float yPPPy, float sh, float shh)
+{
+    float a = (MIN_VAL > yPy) ? MIN_VAL : yPy, b = (MIN_VAL > yPPy) ? MIN_VAL : yPPy, e = (MIN_VAL > yPPPy) ? MIN_VAL : yPPPy;
+    float G2 = (float)(((double)(a + e) - 2.0 * (double)b) / (double)(lam * lam));   /* pyx:1597 */
+    float G1 = (a - b) / lam;                                                /* pyx:1598 */
+    float t = 0.5f * ((((float)n + shh)) - 2.0f * sh);                       /* pyx:1600 numerator (float32 scalars) */
+    float r = (float)((double)t / ((double)lam * (double)lam));              /* / np.power(lam, 2): float64 */
+    r = (float)((double)r - ((0.5 * (double)n) * ((2.0 * (double)G2) - (double)((G1 * G1) / a))) / (double)a);   /* pyx:1601 */
+    return r;
+}
+static float snp_ml_d1(snp_ctx_t *s, float lam)
+{
+    eval_t e; snp_eval(s, lam, 0, &e);
+    return orc_ml_d1(lam, (int)s->n, e.yPy, e.yPPy, e.sh);
+}
+static double ml_d1_as_double(double x, void *user) { return (double)snp_ml_d1((snp_ctx_t *)user, (float)x); }
+static float snp_ml_logl(snp_ctx_t *s, float lam)
+{
+    eval_t e; snp_eval(s, lam, 0, &e);
+    return orc_ml_logl((int)s->n, e.yPy, orc_logdet_H(lam, s->d, s->n));
+}
+/* calc_lambda (lmm/lmm.py:22-84): roots = {1e-5, 1e5} + per decade with a sign change of dlogL/dlambda one
+ * brentq(rtol=0.1, maxiter=5000) refined by scipy.optimize.newton(fprime=d2, rtol=1e-5, tol=1.48e-8, maxiter=10, disp=False)
+ * (SciPy 1.15.3 _zeros_py.py, Newton-Raphson branch: p = p0 - f/f'; stop on f == 0, f' == 0 or isclose(p, p0)); returns the
+ * root with the largest likelihood_lambda (np.argmax: first maximum, a NaN wins).  *logl_out = that likelihood. */
+static float snp_calc_lambda_ml(snp_ctx_t *s, float *logl_out)
+{
+    double roots[16];
+    int nr = 0;
+    roots[nr++] = pow(10.0, -5.0); roots[nr++] = pow(10.0, 5.0);             /* lmm.py:44 */
+    float f0 = 0.0f, f1 = 0.0f;
+    for (int k = -5; k < 5; k++) {                                           /* lmm.py:48-77 */
+        float l0 = orc_pow10f(k), l1 = orc_pow10f(k + 1);                    /* 10.0 ** np.float32(k): float32 under NEP 50 */
+        if (k == -5) f0 = snp_ml_d1(s, l0); else f0 = f1;
+        f1 = snp_ml_d1(s, l1);
+        double s0 = (f0 > 0) - (f0 < 0), s1 = (f1 > 0) - (f1 < 0);           /* np.sign; NaN compares False */
+        if (f0 != f0 || f1 != f1) continue;
+        if (s0 * s1 < 0) {
+            int st;
+            double p0 = orc_brentq(ml_d1_as_double, s, (double)l0, (double)l1, 2e-12, 0.1, 5000, NULL, NULL, &st);
+            double p = p0;
+            for (int itr = 0; itr < 10; itr++) {
+                eval_t e; snp_eval(s, (float)p0, 1, &e);
+                float fval = orc_ml_d1((float)p0, (int)s->n, e.yPy, e.yPPy, e.sh);
+                if (fval == 0) { p = p0; break; }
+                float fder = orc_ml_d2((float)p0, (int)s->n, e.yPy, e.yPPy, e.yPPPy, e.sh, e.shh);
+                if (fder == 0) { p = p0; break; }
+                float step = fval / fder;                                    /* np.float32 / np.float32 */
+                p = p0 - (double)step;                                       /* np.float64 - np.float32 */
+                if (fabs(p - p0) <= 1.48e-8 + 1e-5 * fabs(p0)) break;        /* np.isclose(p, p0, rtol, atol) */
+                p0 = p;
+            }
+            roots[nr++] = p;
+        }
+    }
+    int best = 0;
+    float bl = snp_ml_logl(s, (float)roots[0]);
+    for (int r = 1; r < nr; r++) {                                           /* lmm.py:81-83 */
+        if (bl != bl) break;                                                 /* np.argmax: the first NaN wins */
+        float l = snp_ml_logl(s, (float)roots[r]);
+        if (l != l || l > bl) { bl = l; best = r; }
+    }
+    if (logl_out) *logl_out = bl;
+    return (float)roots[best];
+}
+/* chi2.sf(D, 1) = erfc(sqrt(D/2)); the reference writes 1 - chi2.cdf (lmm.py:300), the same number above ~1e-16 */
+double orc_chi2_sf1(double D) { return (D != D) ? D : (D <= 0.0 ? 1.0 : erfc(sqrt(0.5 * D))); }
+
+/* single-model entry: lambda_ML and its log-likelihood for covariate matrix Wx (n x ctot) — null model (Wx = W) or one SNP */
+float orc_calc_lambda_ml(const float *d, const float *y, const float *Wx, long n, int ctot, int order, float *logl)
+{
+    float *buf = (float *)malloc(sizeof(float) * (size_t)n * ctot);
+    snp_ctx_t s; mk_ctx(&s, buf, d, Wx, y, n, ctot, order);
+    float lam = snp_calc_lambda_ml(&s, logl);
+    free(buf);
+    return lam;
+}
+/* the three ML scalars at one lambda from this file's quadratic forms: out = {logL, d1, d2} */
+void orc_ml_functions(float lam, const float *d, const float *y, const float *Wx, long n, int ctot, int order, float *out3)
+{
+    float *buf = (float *)malloc(sizeof(float) * (size_t)n * ctot);
+    snp_ctx_t s; mk_ctx(&s, buf, d, Wx, y, n, ctot, order);
+    eval_t e; snp_eval(&s, lam, 1, &e);
+    out3[0] = orc_ml_logl((int)n, e.yPy, orc_logdet_H(lam, d, n));
+    out3[1] = orc_ml_d1(lam, (int)n, e.yPy, e.yPPy, e.sh);
+    out3[2] = orc_ml_d2(lam, (int)n, e.yPy, e.yPPy, e.yPPPy, e.sh, e.shh);
+    free(buf);
+}
+/* per-SNP LRT over a block: l_alt[g], lam_alt[g]; l_null from the covariates alone; D = 2(l_alt - l_null) in float32 */
+int orc_calculate_lrt(const float *d, const float *y, const float *W, const float *X, long ld_elem, long ld_snp,
+                      long n, int c, long p, int order, int nthreads, float *l_alt, float *lam_alt, float *l_null, float *lam_null,
+                      float *D, double *p_lrt)
+{
+    if (c + 2 > ORC_MAXM) return -1;
+    float *Wc = (float *)malloc(sizeof(float) * (size_t)n * (size_t)(c > 0 ? c : 1));
+    for (int j = 0; j < c; j++) for (long i = 0; i < n; i++) Wc[(size_t)j * n + i] = W[(size_t)i * c + j];
+    float ln = 0.0f;
+    {
+        snp_ctx_t s0; s0.n = n; s0.ctot = c; s0.d = d; s0.order = order; s0.n_eval_fast = s0.n_eval_full = 0;
+        for (int j = 0; j < c; j++) s0.cols[j] = Wc + (size_t)j * n;
+        s0.cols[c] = y;
+        float lam0 = snp_calc_lambda_ml(&s0, &ln);
+        if (l_null) *l_null = ln;
+        if (lam_null) *lam_null = lam0;
+    }
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+    {
+        float *xb = (float *)malloc(sizeof(float) * (size_t)n);
+        snp_ctx_t s;
+        s.n = n; s.ctot = c + 1; s.d = d; s.order = order; s.n_eval_fast = s.n_eval_full = 0;
+        for (int j = 0; j < c; j++) s.cols[j] = Wc + (size_t)j * n;
+        s.cols[c] = xb; s.cols[c + 1] = y;
+#pragma omp for schedule(dynamic, 4)
+        for (long g = 0; g < p; g++) {
+            for (long i = 0; i < n; i++) xb[i] = X[(size_t)i * ld_elem + (size_t)g * ld_snp];
+            float la;
+            float lam = snp_calc_lambda_ml(&s, &la);
+            l_alt[g] = la; lam_alt[g] = lam;
+            float Dg = 2.0f * (la - ln);                                     /* lmm.py:283  np.float32 scalars */
+            D[g] = Dg;
+            p_lrt[g] = orc_chi2_sf1((double)Dg);                             /* lmm.py:300 */
+        }
+        free(xb);
+    }
+    free(Wc);
+    return 0;
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP

@@ -22,7 +22,7 @@ SYMBOLS = [
     "pg_memcpy_d2d_async", "pg_memcpy2d_h2d_async", "pg_stage_rows", "pg_event_sync", "pg_stream_wait_event",
     "pg_comm_unique_id", "pg_comm_init_rank", "pg_comm_init_all", "pg_comm_destroy", "pg_comm_size", "pg_comm_rank",
     "pg_comm_broadcast_dev", "pg_comm_allgather_dev", "pg_comm_allreduce_f64_dev", "pg_comm_barrier", "pg_comm_group_start",
-    "pg_comm_group_end", "pgx_dgemm_dev", "pgx_sytrd_dev", "pgx_stedc_dev", "pg_kinship_geno_dev",
+    "pg_comm_group_end", "pgx_dgemm_dev", "pgx_sytrd_dev", "pgx_stedc_dev", "pg_kinship_geno_dev", "pg_assoc_lrt_dev",
 ]
 
 
@@ -56,6 +56,8 @@ def load():
     L.pg_memset.argtypes = [vp, vp, i32, sz]
     L.pg_assoc_dev.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]
     L.pg_assoc.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.pg_assoc_lrt_dev.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp, i64, i32] + [vp] * 10
+    L.pg_assoc_lrt_dev.restype = i32
     L.pg_fdist_sf_dev.argtypes = [vp, i64, vp, C.c_double, vp]
     L.pg_assoc_multi.argtypes = [i32, i64, i32, i64, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.pg_assoc_multi.restype = i32

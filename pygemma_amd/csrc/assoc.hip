@@ -63,9 +63,14 @@ struct AssocParams {
     float *beta, *se, *tau, *lam;
     double *F;
     unsigned long long *stats;
+    // N2 (LRT instantiations only): ML lambda and log-likelihood per SNP; ml_c = f32(f32((n/2) ln(n/2pi)) - (n/2)) (pyx:1552-1554)
+    int lrt, nhalf;
+    float ml_c;
+    float *lalt, *lamalt;
 };
 
-struct EvalOut { float yPy, yPPy, yPPPy, trP, trPP, ld, Pxx_c, Pyx_c; };
+// quadratic forms of one evaluation; sh, shh = the level-0 (un-projected) traces sum h, sum h^2 the ML functions use
+struct EvalOut { float yPy, yPPy, yPPPy, trP, trPP, ld, Pxx_c, Pyx_c, sh, shh; };
 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float hinv_f32(float lam, float d)
@@ -196,6 +201,36 @@ __device__ __forceinline__ float d2_f(const AssocParams &pr, float lam, float yP
     float r = (float)((0.5 * ((double)nct - 2.0 * (double)trP)) / lam2);
     float G2a = __fmul_rn(G2, a);
     r = (float)((double)r - ((double)pr.nu * ((double)G2a - (0.5 * (double)G1) * (double)G1)) / ((double)a * (double)a));
+    return r;
+}
+
+// N2: the ML (non-restricted) scalars — likelihood_lambda pyx:1542-1562, likelihood_derivative1_lambda pyx:1567-1581,
+// likelihood_derivative2_lambda pyx:1586-1603 — same statements and widths as oracle orc_ml_logl / orc_ml_d1 / orc_ml_d2
+// (the reference takes the quadratic forms from float32 NumPy helpers; here they come from the sweeps: tolerance parity,
+// see oracle/pygemma_oracle.c).
+__device__ __forceinline__ float ml_logl_f(const AssocParams &pr, float yPy, float ldH)
+{
+    float r = pr.ml_c;                                                       // pyx:1552-1554 folded on the host
+    r = __fsub_rn(r, __fmul_rn(0.5f, ldH));                                  // pyx:1556
+    const float t = (PG_MINV > yPy) ? PG_MINV : yPy;
+    r = (float)((double)r - (double)pr.nhalf * log((double)t));              // pyx:1558
+    return r;
+}
+__device__ __forceinline__ float ml_d1_f(const AssocParams &pr, float lam, float yPy, float yPPy, float sh)
+{
+    float r = __fmul_rn(-0.5f, __fdiv_rn(__fsub_rn((float)pr.n, sh), lam));  // pyx:1574
+    const float num = (PG_MINV > yPPy) ? PG_MINV : yPPy, den = (PG_MINV > yPy) ? PG_MINV : yPy;
+    r = (float)((double)r + ((double)pr.nhalf * (1.0 - (double)__fdiv_rn(num, den))) / (double)lam);   // pyx:1579
+    return r;
+}
+__device__ __forceinline__ float ml_d2_f(const AssocParams &pr, float lam, float yPy, float yPPy, float yPPPy, float sh, float shh)
+{
+    const float a = (PG_MINV > yPy) ? PG_MINV : yPy, b = (PG_MINV > yPPy) ? PG_MINV : yPPy, e = (PG_MINV > yPPPy) ? PG_MINV : yPPPy;
+    const float G2 = (float)(((double)__fadd_rn(a, e) - 2.0 * (double)b) / (double)__fmul_rn(lam, lam));   // pyx:1597
+    const float G1 = __fdiv_rn(__fsub_rn(a, b), lam);                                                    // pyx:1598
+    const float t = __fmul_rn(0.5f, __fsub_rn(__fadd_rn((float)pr.n, shh), __fmul_rn(2.0f, sh)));        // pyx:1600
+    float r = (float)((double)t / ((double)lam * (double)lam));
+    r = (float)((double)r - ((0.5 * (double)pr.n) * ((2.0 * (double)G2) - (double)__fdiv_rn(__fmul_rn(G1, G1), a))) / (double)a);   // pyx:1601
     return r;
 }
 
@@ -355,6 +390,8 @@ __device__ __forceinline__ void lane_sweeps(double (&P)[Shape<C>::SLOTS], double
     o.trP = (float)trP;
     o.trPP = FULL ? (float)trPP : 0.0f;
     o.ld = ld;
+    o.sh = (float)t1;
+    o.shh = FULL ? (float)t2 : 0.0f;
 }
 
 // One element's operands: the packed fixed row (d, w_0..w_{C-1}, y) as 16-byte vectors plus x_i.
@@ -641,13 +678,13 @@ __device__ __forceinline__ void wave_lds_sync()
 // scipy.optimize.brentq (scipy/optimize/Zeros/brentq.c), xtol=2e-12, rtol=0.1, maxiter=100 (pyx:176-182).
 // f(a), f(b) are the decade-scan values (the reference re-evaluates them: same inputs, same results).
 template <class Fn>
-__device__ __forceinline__ double brentq_dev(Fn &&f, double xa, double xb, double fa, double fb)
+__device__ __forceinline__ double brentq_dev(Fn &&f, double xa, double xb, double fa, double fb, int maxiter = 100)
 {
     const double xtol = 2e-12, rtol = 0.1;
     double xpre = xa, xcur = xb, xblk = 0., fpre = fa, fcur = fb, fblk = 0., spre = 0., scur = 0., sbis, delta, stry, dpre, dblk;
     if (fpre == 0) return xpre;
     if (fcur == 0) return xcur;
-    for (int i = 0; i < 100; i++) {
+    for (int i = 0; i < maxiter; i++) {
         if (fpre != 0 && fcur != 0 && (__builtin_signbit(fpre) != __builtin_signbit(fcur))) {
             xblk = xpre; fblk = fpre; spre = scur = xcur - xpre;
         }
@@ -708,7 +745,7 @@ __device__ __forceinline__ float newton_dev(const AssocParams &pr, float lroot, 
     return lroot;
 }
 
-template <int C>
+template <int C, bool LRT>
 // two waves per SIMD: a lone wave cannot issue fp64 VALU at the pipe's rate (measured 2.3x faster at 2 than at 1;
 // <= 256 VGPRs at c <= 6 with a handful of spills outside the hot loops); larger c keeps one wave and its registers
 __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams pr)
@@ -791,6 +828,56 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
             if (ll > best_l) { best_l = ll; best_lambda = lroot; best_e = e; }
         }
     }
+    if constexpr (LRT) {
+        // ---- N2: lambda_ML = calc_lambda(eigenVals, Y, [W, x]) (lmm/lmm.py:22-84) and likelihood_lambda at it (pyx:1542-1562).
+        // Candidates in the reference's order: 1e-5, 1e5, then per decade with a sign change of d logL / d lambda one root by
+        // brentq(rtol = 0.1, maxiter = 5000) + scipy.optimize.newton(fprime = d2, rtol = 1e-5, tol = 1.48e-8, maxiter = 10);
+        // np.argmax keeps the first maximum (a NaN wins).  The decade values reuse the scan's quadratic forms.
+        float ml_l = ml_logl_f(pr, evs[0].yPy, pr.ldHtab[0]), ml_lam = pr.lam11[0];
+        {
+            const float l1 = ml_logl_f(pr, evs[NLAM - 1].yPy, pr.ldHtab[NLAM - 1]);
+            if (ml_l == ml_l && (l1 != l1 || l1 > ml_l)) { ml_l = l1; ml_lam = pr.lam11[NLAM - 1]; }
+        }
+        for (int k = 0; k < NLAM - 1; k++) {
+            const float f0 = ml_d1_f(pr, pr.lam11[k], evs[k].yPy, evs[k].yPPy, evs[k].sh);
+            const float f1 = ml_d1_f(pr, pr.lam11[k + 1], evs[k + 1].yPy, evs[k + 1].yPPy, evs[k + 1].sh);
+            if (f0 != f0 || f1 != f1) continue;
+            const float s0 = (float)((f0 > 0) - (f0 < 0)), s1 = (float)((f1 > 0) - (f1 < 0));
+            if (!(s0 * s1 < 0.0f)) continue;                                 // np.sign(f0) * np.sign(f1) < 0
+            double p0 = brentq_dev(
+                [&](double x) -> double {
+                    EvalOut e;
+                    const float lf = (float)x;
+                    eval_specific<C, false>(pr, xrow, lf, lane, own, e);
+                    n_fast++;
+                    return (double)ml_d1_f(pr, lf, e.yPy, e.yPPy, e.sh);
+                },
+                (double)pr.lam11[k], (double)pr.lam11[k + 1], (double)f0, (double)f1, 5000);
+            double pn = p0;
+            for (int itr = 0; itr < 10; itr++) {
+                EvalOut e;
+                const float lf = (float)p0;
+                eval_specific<C, true>(pr, xrow, lf, lane, own, e);
+                n_full++;
+                const float fval = ml_d1_f(pr, lf, e.yPy, e.yPPy, e.sh);
+                if (fval == 0.0f) { pn = p0; break; }
+                const float fder = ml_d2_f(pr, lf, e.yPy, e.yPPy, e.yPPPy, e.sh, e.shh);
+                if (fder == 0.0f) { pn = p0; break; }
+                pn = p0 - (double)__fdiv_rn(fval, fder);
+                if (fabs(pn - p0) <= 1.48e-8 + 1e-5 * fabs(p0)) break;
+                p0 = pn;
+            }
+            if (ml_l == ml_l) {
+                EvalOut e;
+                const float lf = (float)pn;
+                eval_specific<C, false>(pr, xrow, lf, lane, own, e);
+                n_fast++;
+                const float l = ml_logl_f(pr, e.yPy, device_logdet_H(pr, lf, lane, vals));
+                if (l != l || l > ml_l) { ml_l = l; ml_lam = lf; }
+            }
+        }
+        if (lane == 0) { pr.lalt[g] = ml_l; pr.lamalt[g] = ml_lam; }
+    }
     // ---- beta, se, tau, F (pyx:1529-1537, lmm.py:471)
     if (lane == 0) {
         const float b = __fdiv_rn(best_e.Pyx_c, best_e.Pxx_c);
@@ -813,53 +900,88 @@ static size_t assoc_lds_bytes(int c, int n_vals)
     return per_wave * WPB;
 }
 
-template <int C>
+template <int C, bool LRT = false>
 static int launch_assoc(pg_ctx *ctx, AssocParams &pr)
 {
     setup_tabs_kernel<C><<<NLAM, 64, (size_t)pr.n_vals * 4 + 16, ctx->stream>>>(pr);
     PG_HIP(hipGetLastError());
     const size_t lds = assoc_lds_bytes(C, pr.n_vals);
     if (lds > 64 * 1024)
-        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&assoc_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&assoc_kernel<C, LRT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long nblk = (pr.p + WPB - 1) / WPB;
-    assoc_kernel<C><<<dim3((unsigned)nblk), 64 * WPB, lds, ctx->stream>>>(pr);
+    assoc_kernel<C, LRT><<<dim3((unsigned)nblk), 64 * WPB, lds, ctx->stream>>>(pr);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
 
 
-// The association kernel is instantiated per covariate count; the instantiations are split over two translation units
-// (assoc.hip: c = 1..15, assoc_hi.hip: c = 16..PG_MAX_COVARIATES) so that they compile in parallel.
+// The association kernel is instantiated per covariate count (and once more with the LRT search, N2); the instantiations
+// are split over translation units so that they compile in parallel:
+//   assoc.hip          c = 1..15            assoc_hi.hip      c = 16..PG_MAX_COVARIATES
+//   assoc_lrt.hip      LRT, c = 0..15       assoc_lrt_hi.hip  LRT, c = 16..PG_MAX_COVARIATES
+// (c = 0 exists for the LRT's null model at c = 1: the covariates alone, run as "c - 1 covariates + the last one as the SNP").
 int launch_assoc_hi(pg_ctx *ctx, AssocParams &pr);
-#ifdef PG_ASSOC_HI
+int launch_assoc_lrt(pg_ctx *ctx, AssocParams &pr);
+int launch_assoc_lrt_hi(pg_ctx *ctx, AssocParams &pr);
+#define PG_CASE(CC) case CC: return launch_assoc<CC, PG_CASE_LRT>(ctx, pr);
+#if defined(PG_ASSOC_PART) && PG_ASSOC_PART == 1
+#define PG_CASE_LRT false
 int launch_assoc_hi(pg_ctx *ctx, AssocParams &pr)
 {
     switch (pr.c) {
-#define PG_CASE(CC) case CC: return launch_assoc<CC>(ctx, pr);
         PG_CASE(16) PG_CASE(17) PG_CASE(18) PG_CASE(19) PG_CASE(20) PG_CASE(21) PG_CASE(22) PG_CASE(23) PG_CASE(24) PG_CASE(25)
         PG_CASE(26) PG_CASE(27) PG_CASE(28) PG_CASE(29) PG_CASE(30)
-#undef PG_CASE
+        default: return PG_ENOTSUP;
+    }
+}
+#elif defined(PG_ASSOC_PART) && PG_ASSOC_PART == 2
+#define PG_CASE_LRT true
+int launch_assoc_lrt(pg_ctx *ctx, AssocParams &pr)
+{
+    switch (pr.c) {
+        PG_CASE(0) PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10)
+        PG_CASE(11) PG_CASE(12) PG_CASE(13) PG_CASE(14) PG_CASE(15)
+        default: return launch_assoc_lrt_hi(ctx, pr);
+    }
+}
+#elif defined(PG_ASSOC_PART) && PG_ASSOC_PART == 3
+#define PG_CASE_LRT true
+int launch_assoc_lrt_hi(pg_ctx *ctx, AssocParams &pr)
+{
+    switch (pr.c) {
+        PG_CASE(16) PG_CASE(17) PG_CASE(18) PG_CASE(19) PG_CASE(20) PG_CASE(21) PG_CASE(22) PG_CASE(23) PG_CASE(24) PG_CASE(25)
+        PG_CASE(26) PG_CASE(27) PG_CASE(28) PG_CASE(29) PG_CASE(30)
         default: return PG_ENOTSUP;
     }
 }
 #else
+#define PG_CASE_LRT false
 static int launch_assoc_any(pg_ctx *ctx, AssocParams &pr)
 {
+    if (pr.lrt) return launch_assoc_lrt(ctx, pr);
     switch (pr.c) {
-#define PG_CASE(CC) case CC: return launch_assoc<CC>(ctx, pr);
 #ifdef PG_ONLY_C
         PG_CASE(PG_ONLY_C)
 #else
         PG_CASE(1) PG_CASE(2) PG_CASE(3) PG_CASE(4) PG_CASE(5) PG_CASE(6) PG_CASE(7) PG_CASE(8) PG_CASE(9) PG_CASE(10)
         PG_CASE(11) PG_CASE(12) PG_CASE(13) PG_CASE(14) PG_CASE(15)
 #endif
-#undef PG_CASE
         default: return launch_assoc_hi(ctx, pr);
     }
 }
+#ifdef PG_ONLY_C   // single-c development builds (A/B timing): the LRT pair c, c-1 in this translation unit, nothing else
+#undef PG_CASE_LRT
+#define PG_CASE_LRT true
+int launch_assoc_lrt(pg_ctx *ctx, AssocParams &pr)
+{
+    switch (pr.c) { PG_CASE(PG_ONLY_C) case PG_ONLY_C - 1: return launch_assoc<PG_ONLY_C - 1, true>(ctx, pr); default: return PG_ENOTSUP; }
+}
+int launch_assoc_hi(pg_ctx *, AssocParams &) { return PG_ENOTSUP; }
 #endif
+#endif
+#undef PG_CASE
 
-#ifndef PG_ASSOC_HI
+#ifndef PG_ASSOC_PART
 // ------------------------------------------------------------------------------------------------
 // scipy.stats.f.sf(F, 1, dfd) (lmm.py:482): I_{w}(dfd/2, 1/2), w = dfd/(dfd+F) — same statements as
 // oracle orc_fdist_sf (continued fraction, modified Lentz).
@@ -905,7 +1027,7 @@ __global__ void fdist_sf_kernel(long long count, const double *F, double dfd, do
 }
 
 // packed fixed rows: d, w_0..w_{c-1}, y, zero pad; rows [n, npad) zero
-__global__ void build_fixed_kernel(int n, int npad, int c, int rowf, const float *d, const float *Wr, const float *yr, float *fixed)
+__global__ void build_fixed_kernel(int n, int npad, int c, int ldw, int rowf, const float *d, const float *Wr, const float *yr, float *fixed)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npad) return;
@@ -913,7 +1035,7 @@ __global__ void build_fixed_kernel(int n, int npad, int c, int rowf, const float
     for (int k = 0; k < rowf; k++) row[k] = 0.0f;
     if (i < n) {
         row[0] = d[i];
-        for (int j = 0; j < c; j++) row[1 + j] = Wr[(size_t)i * c + j];
+        for (int j = 0; j < c; j++) row[1 + j] = Wr[(size_t)i * ldw + j];
         row[c + 1] = yr[i];
     }
 }
@@ -1132,18 +1254,12 @@ extern "C" int pg_transpose_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *
     return PG_OK;
 }
 
-extern "C" int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
-                            const float *Xr, int64_t ldx, int grid, float *beta, float *se, float *tau, float *lambda,
-                            double *F, double *pval, unsigned long long *stats_dev)
+// fixed rows + tables + the kernel for one (covariates, SNP block); Wr is n x c with row stride ldw >= c (the LRT's null model
+// passes the first c columns of a wider matrix)
+static int assoc_run(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, int64_t ldw, const float *yr,
+                     const float *Xr, int64_t ldx, int grid, float *beta, float *se, float *tau, float *lambda, double *F,
+                     unsigned long long *stats_dev, bool lrt, float *lalt, float *lamalt)
 {
-    PG_REQUIRE(ctx && d && Wr && yr && Xr && beta && se && tau && lambda && F, "pg_assoc_dev: NULL argument");
-    PG_REQUIRE(n >= 2 && n < (1LL << 30) && p >= 0 && ldx >= n, "pg_assoc_dev: bad shape n=%lld p=%lld ldx=%lld", (long long)n, (long long)p, (long long)ldx);
-    if (c < 1 || c > PG_MAX_COVARIATES) {
-        set_error("pg_assoc_dev: c=%d covariates not supported by this build (1..%d)", c, PG_MAX_COVARIATES);
-        return PG_ENOTSUP;
-    }
-    PG_REQUIRE(n - c - 1 > 0, "pg_assoc_dev: n - c - 1 must be positive");
-    if (p == 0) return PG_OK;
     PG_HIP(hipSetDevice(ctx->device));
     int rc = build_npsum_plan(ctx, n);
     if (rc) return rc;
@@ -1173,16 +1289,97 @@ extern "C" int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const floa
         r = (float)((double)r - (0.5 * (double)(n - ctot)));                                          // pyx:1822
         pr.logl_c = r;
     }
+    pr.lrt = lrt ? 1 : 0;
+    pr.nhalf = (int)(n / 2);                                                                          // (n/2): C integer division
+    {
+        float r = (float)((double)(n / 2) * std::log((double)n / (2.0 * M_PI)));                      // pyx:1552
+        pr.ml_c = r - (float)(n / 2);                                                                 // pyx:1554
+    }
+    pr.lalt = lalt; pr.lamalt = lamalt;
     pr.leaf = ctx->plan.d_leaf; pr.node = ctx->plan.d_node; pr.level = ctx->plan.d_level; pr.chunk = ctx->plan.d_chunk;
     pr.n_leaf = ctx->plan.n_leaf; pr.n_level = ctx->plan.n_level; pr.n_chunk = ctx->plan.n_chunk;
     pr.n_vals = ctx->plan.n_leaf + ctx->plan.n_node;
     pr.beta = beta; pr.se = se; pr.tau = tau; pr.lam = lambda; pr.F = F;
     pr.stats = stats_dev;
 
-    build_fixed_kernel<<<(pr.npad + 255) / 256, 256, 0, ctx->stream>>>(pr.n, pr.npad, c, pr.rowf, d, Wr, yr, (float *)ctx->fixed);
+    build_fixed_kernel<<<(pr.npad + 255) / 256, 256, 0, ctx->stream>>>(pr.n, pr.npad, c, (int)ldw, pr.rowf, d, Wr, yr, (float *)ctx->fixed);
     PG_HIP(hipGetLastError());
-    rc = launch_assoc_any(ctx, pr);
+    return launch_assoc_any(ctx, pr);
+}
+
+extern "C" int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
+                            const float *Xr, int64_t ldx, int grid, float *beta, float *se, float *tau, float *lambda,
+                            double *F, double *pval, unsigned long long *stats_dev)
+{
+    PG_REQUIRE(ctx && d && Wr && yr && Xr && beta && se && tau && lambda && F, "pg_assoc_dev: NULL argument");
+    PG_REQUIRE(n >= 2 && n < (1LL << 30) && p >= 0 && ldx >= n, "pg_assoc_dev: bad shape n=%lld p=%lld ldx=%lld", (long long)n, (long long)p, (long long)ldx);
+    if (c < 1 || c > PG_MAX_COVARIATES) {
+        set_error("pg_assoc_dev: c=%d covariates not supported by this build (1..%d)", c, PG_MAX_COVARIATES);
+        return PG_ENOTSUP;
+    }
+    PG_REQUIRE(n - c - 1 > 0, "pg_assoc_dev: n - c - 1 must be positive");
+    if (p == 0) return PG_OK;
+    int rc = assoc_run(ctx, n, c, p, d, Wr, c, yr, Xr, ldx, grid, beta, se, tau, lambda, F, stats_dev, false, nullptr, nullptr);
     if (rc) return rc;
+    if (pval) return pg_fdist_sf_dev(ctx, p, F, (double)(n - c - 1), pval);
+    return PG_OK;
+}
+
+namespace pg {
+__global__ void gather_col_kernel(int n, int npad, const float *W, int ldw, int col, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) out[i] = (i < n) ? W[(size_t)i * ldw + col] : 0.0f;
+}
+// D_lrt = 2 (l_alt - l_null) on float32 scalars (lmm/lmm.py:283), p_lrt = chi2(1).sf(D_lrt) = erfc(sqrt(D/2)) (lmm.py:300 writes
+// 1 - cdf: the same number above ~1e-16); all four columns widened to float64 like the frame's lambda column
+__global__ void lrt_finish_kernel(long long p, const float *lalt, const float *lnull, double *o_lalt, double *o_lnull, double *o_D, double *o_p)
+{
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p) return;
+    const float la = lalt[g], ln = lnull[0];
+    const float D = __fmul_rn(2.0f, __fsub_rn(la, ln));
+    const double Dd = (double)D;
+    o_lalt[g] = (double)la; o_lnull[g] = (double)ln; o_D[g] = Dd;
+    o_p[g] = (Dd != Dd) ? Dd : (Dd <= 0.0 ? 1.0 : erfc(sqrt(0.5 * Dd)));
+}
+}  // namespace pg
+
+// ---- N2: pg_assoc_dev plus the likelihood-ratio columns the reference sketches and leaves commented out
+// (lmm/lmm.py:137-141, 277-300) from its own ML functions (calc_lambda lmm.py:22-84; likelihood_lambda and derivatives
+// pygemma_model.pyx:1542-1603).  Same kernel, instantiated with the ML lambda search appended: the decade scan is shared with the
+// REML search (its quadratic forms serve both), roots are refined by brentq + Newton like the reference's scipy calls.
+// l_null comes from the same kernel run on the covariates alone (c - 1 covariates + the last one in the SNP's place).
+extern "C" int pg_assoc_lrt_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const float *Wr, const float *yr,
+                                const float *Xr, int64_t ldx, int grid, float *beta, float *se, float *tau, float *lambda,
+                                double *F, double *pval, double *l_alt, double *l_null, double *D_lrt, double *p_lrt)
+{
+    PG_REQUIRE(ctx && d && Wr && yr && Xr && beta && se && tau && lambda && F && l_alt && l_null && D_lrt && p_lrt, "pg_assoc_lrt_dev: NULL argument");
+    PG_REQUIRE(n >= 2 && n < (1LL << 30) && p >= 0 && ldx >= n, "pg_assoc_lrt_dev: bad shape");
+    if (c < 1 || c > PG_MAX_COVARIATES) {
+        set_error("pg_assoc_lrt_dev: c=%d covariates not supported by this build (1..%d)", c, PG_MAX_COVARIATES);
+        return PG_ENOTSUP;
+    }
+    PG_REQUIRE(n - c - 1 > 0, "pg_assoc_lrt_dev: n - c - 1 must be positive");
+    if (p == 0) return PG_OK;
+    PG_HIP(hipSetDevice(ctx->device));
+    const int64_t npad = (n + 63) / 64 * 64;
+    // scratch: [x_null (npad f32) | null outputs: 4 f32 + 1 f64 | l_null f32 | lam_null f32 | l_alt (p f32) | lam_alt (p f32)]
+    const size_t off_out = (size_t)npad * 4, off_la = off_out + 64, need = off_la + (size_t)p * 8 + 64;
+    int rc = ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, need);
+    if (rc) return rc;
+    char *sc = (char *)ctx->scratch;
+    float *xnull = (float *)sc, *nb = (float *)(sc + off_out), *lnull = nb + 8, *lamnull = nb + 9;
+    double *nF = (double *)(sc + off_out + 16);
+    float *lalt = (float *)(sc + off_la), *lamalt = lalt + p;
+    gather_col_kernel<<<(unsigned)((npad + 255) / 256), 256, 0, ctx->stream>>>((int)n, (int)npad, Wr, c, c - 1, xnull);
+    PG_HIP(hipGetLastError());
+    rc = assoc_run(ctx, n, c - 1, 1, d, Wr, c, yr, xnull, npad, grid, nb, nb + 1, nb + 2, nb + 3, nF, nullptr, true, lnull, lamnull);
+    if (rc) return rc;
+    rc = assoc_run(ctx, n, c, p, d, Wr, c, yr, Xr, ldx, grid, beta, se, tau, lambda, F, nullptr, true, lalt, lamalt);
+    if (rc) return rc;
+    lrt_finish_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, lalt, lnull, l_alt, l_null, D_lrt, p_lrt);
+    PG_HIP(hipGetLastError());
     if (pval) return pg_fdist_sf_dev(ctx, p, F, (double)(n - c - 1), pval);
     return PG_OK;
 }
@@ -1258,4 +1455,4 @@ extern "C" int pg_reml_scalars_dev(pg_ctx *ctx, int64_t n, int ctot, const float
 }
 #else
 }  // namespace pg
-#endif  // PG_ASSOC_HI
+#endif  // PG_ASSOC_PART

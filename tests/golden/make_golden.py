@@ -307,3 +307,44 @@ def gen_reference_test_matrices():
 
 if __name__ == "__main__" and "refmat" in sys.argv[1:]:
     gen_reference_test_matrices()
+
+
+def gen_lrt():
+    """N2: the ML functions and the LRT the reference sketches (lmm/lmm.py:22-84, 277-300; pyx:1542-1603), by CALLING the
+    real reference: likelihood_lambda / likelihood_derivative1_lambda / likelihood_derivative2_lambda on a lambda list,
+    calc_lambda per SNP ([W, x]) and for the null model (W), and the D_lrt / p_lrt the commented-out lines would compute
+    (l from likelihood_lambda at calc_lambda's root — the sketch's likelihood(lambda, tau=n/yPy, beta_GLS) is that number
+    analytically).  Panels are regenerated from synth.rotated_panel (inputs stored too)."""
+    out = {"versions": VERS, "lams": np.array(LAMS, np.float32)}
+    for name, (n, p, c, seed, null, h2) in {"sig": (400, 160, 5, 21, False, 0.5), "weak": (300, 120, 3, 22, False, 0.04),
+                                              "null": (320, 80, 10, 23, True, 0.5), "c1": (257, 60, 1, 24, False, 0.5)}.items():
+        rp = synth.rotated_panel(n, p, c, seed=seed, null=null, h2=h2)
+        d, Y, W, X = rp["d"], rp["Y"], np.ascontiguousarray(rp["W"]), np.ascontiguousarray(rp["X"])
+        for k, v in (("d", d), ("Y", Y), ("W", W), ("X", X)):
+            out[f"{name}_{k}"] = v
+        lam0 = quiet(ref.calc_lambda, d, Y, W)
+        l0 = np.float32(ref.likelihood_lambda(np.float32(lam0), d, Y, W))
+        out[f"{name}_lambda_null"], out[f"{name}_l_null"] = np.float64(lam0), l0
+        la, ll = np.empty(p, np.float64), np.empty(p, np.float32)
+        for g in range(p):
+            Wx = np.ascontiguousarray(np.c_[W, X[:, g]]).astype(np.float32)
+            la[g] = quiet(ref.calc_lambda, d, Y, Wx)
+            ll[g] = ref.likelihood_lambda(np.float32(la[g]), d, Y, Wx)
+        D = (2 * (ll - l0)).astype(np.float32)                              # lmm.py:283 on np.float32 scalars
+        out[f"{name}_lambda_alt"], out[f"{name}_l_alt"], out[f"{name}_D_lrt"] = la, ll, D
+        out[f"{name}_p_lrt"] = 1 - scipy.stats.chi2.cdf(x=D.astype(np.float64), df=1)   # lmm.py:300
+        out[f"{name}_p_lrt_sf"] = scipy.stats.chi2.sf(D.astype(np.float64), 1)
+        # the three ML scalars on the first two SNPs (+ the null model) over the lambda list
+        fn = np.empty((3, len(LAMS), 3), np.float32)
+        for si, Wx in enumerate([W, np.c_[W, X[:, 0]].astype(np.float32), np.c_[W, X[:, 1]].astype(np.float32)]):
+            Wx = np.ascontiguousarray(Wx)
+            for li, lam in enumerate(LAMS):
+                fn[si, li] = [ref.likelihood_lambda(np.float32(lam), d, Y, Wx), ref.likelihood_derivative1_lambda(np.float32(lam), d, Y, Wx),
+                              ref.likelihood_derivative2_lambda(np.float32(lam), d, Y, Wx)]
+        out[f"{name}_ml_functions"] = fn
+        print(name, "lambda_null", lam0, "l_null", l0, "D_lrt max", D.max(), "boundary roots", int((la <= 1.01e-5).sum()), int((la >= 9.9e4).sum()))
+    np.savez_compressed(os.path.join(HERE, "lrt_panels.npz"), **out)
+
+
+if __name__ == "__main__" and "lrt" in sys.argv[1:]:
+    gen_lrt()

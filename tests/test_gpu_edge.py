@@ -21,7 +21,9 @@ def ctx():
 
 @pytest.mark.parametrize("n,p,c", [(40, 5, 1), (65, 70, 2), (130, 33, 4), (96, 20, 6), (150, 24, 7), (128, 16, 8), (200, 12, 9),
                                    (90, 9, 11), (257, 10, 12), (64, 1, 3), (1000, 7, 5), (300, 6, 10), (120, 5, 13), (333, 9, 14),
-                                   (200, 4, 15), (129, 3, 16), (500, 6, 17), (260, 5, 18), (192, 2, 19), (400, 7, 20)])
+                                   (200, 4, 15), (129, 3, 16), (500, 6, 17), (260, 5, 18), (192, 2, 19), (400, 7, 20),
+                                   # the reference's covariate benchmark runs PCS+1 in {1,6,11,16,21,26} (experiments/animal_gwas/benchmark_pygemma.py:238-255)
+                                   (300, 5, 21), (222, 3, 23), (450, 6, 26), (193, 2, 29), (384, 4, 30)])
 @pytest.mark.parametrize("grid", [False, True])
 def test_all_covariate_counts_and_ragged_shapes(n, p, c, grid, ctx):
     from oracle import oracle as O
@@ -47,7 +49,7 @@ def test_empty_block_and_bad_arguments(ctx):
     assert L.pg_assoc(ctx.handle, 64, 2, 0, vp(d), vp(W), vp(y), vp(z), 0, vp(z), vp(z), vp(z), vp(z), vp(z), vp(z), None) == 0
     # unsupported number of covariates: loud, with a message, no crash
     with pytest.raises(_lib.PgError, match="covariates not supported"):
-        ops.assoc(rp["d"], np.ones((64, 21), np.float32), rp["Y"], rp["X"], ctx=ctx)
+        ops.assoc(rp["d"], np.ones((64, 31), np.float32), rp["Y"], rp["X"], ctx=ctx)
     # NULL pointer
     assert L.pg_assoc(ctx.handle, 64, 2, 4, None, vp(W), vp(y), vp(z), 0, vp(z), vp(z), vp(z), vp(z), vp(z), vp(z), None) < 0
     assert b"NULL" in L.pg_last_error()

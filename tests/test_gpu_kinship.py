@@ -26,7 +26,7 @@ def test_kinship_matches_float64_reference(n, p):
     assert (K.view(np.uint32) == K.T.copy().view(np.uint32)).all()          # mirrored, bit-symmetric
     scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
     assert np.abs(K - ref).max() <= 1e-6 * scale.max() * np.sqrt(p) / 8      # fp32 accumulation over p terms
-    assert np.abs(K - ref).max() / np.abs(ref).max() <= 2e-6
+    assert np.abs(K - ref).max() / np.abs(ref).max() <= 1e-6 + 6e-8 * np.sqrt(p)   # random-walk growth of the fp32 accumulation
 
 
 def test_kinship_without_standardisation_and_feeds_eigensolver():

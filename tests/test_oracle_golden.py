@@ -212,3 +212,46 @@ def test_reference_own_test_matrices_degenerate_collinear_snp():
         assert np.isfinite(a) == np.isfinite(b)
         # the x pivot is the difference of two ~equal numbers: agreement to a few per cent is all that is defined here
         assert abs(a - b) <= (1e-4 if col == "tau" else 5e-2) * abs(b)
+
+
+# ---- N2: ML functions + LRT (tolerance parity: the reference's quadratic forms come from float32 NumPy helpers) ---------------
+@pytest.mark.parametrize("name", ["sig", "weak", "null", "c1"])
+@pytest.mark.parametrize("order", [0, 1])
+def test_lrt_oracle_vs_reference_fixtures(name, order):
+    """calc_lambda (lmm/lmm.py:22-84) + likelihood_lambda (pyx:1542-1562) per SNP and for the null model, D_lrt and p_lrt as the
+    commented-out lines would form them (lmm.py:277-300): oracle vs the real reference's own functions (tests/golden/lrt_panels.npz).
+    Tolerances = the reference's float32 noise: log-likelihoods within 2 float32 ulp, D within 2 quanta, lambda 5e-5."""
+    z = np.load(os.path.join(G, "lrt_panels.npz"))
+    d, Y, W, X = (z[f"{name}_{k}"] for k in "dYWX")
+    r = O.calculate_lrt(d, Y, W, X, order=order, nthreads=4)
+    ulp = np.spacing(np.float32(abs(float(z[f"{name}_l_null"]))))
+    assert abs(r["l_null"] - float(z[f"{name}_l_null"])) <= 2 * ulp
+    assert abs(r["lambda_null"] / float(z[f"{name}_lambda_null"]) - 1) <= 5e-5
+    assert np.abs(r["l_alt"].astype(np.float64) - z[f"{name}_l_alt"]).max() <= 2 * ulp
+    assert np.abs(r["D_lrt"].astype(np.float64) - z[f"{name}_D_lrt"]).max() <= 4 * ulp + 1e-6
+    assert np.abs(r["lambda_alt"] / z[f"{name}_lambda_alt"] - 1).max() <= 5e-5
+    ref_p = z[f"{name}_p_lrt_sf"]
+    assert np.abs(r["p_lrt"] / ref_p - 1).max() <= 5e-3
+    big = z[f"{name}_p_lrt"] > 1e-10                 # the reference's 1 - cdf form is the same number where it has digits
+    np.testing.assert_allclose(z[f"{name}_p_lrt"][big], ref_p[big], rtol=1e-5)
+
+
+def test_ml_scalar_functions_vs_reference_fixtures():
+    """likelihood_lambda / likelihood_derivative1_lambda / likelihood_derivative2_lambda (pyx:1542-1603) on the lambda list:
+    logL agrees to float32 rounding wherever the reference's float32 projector is well conditioned (lambda <= 400; 2e-6 at 1e3); the
+    derivatives, which the reference forms by cancellation in float32, within 1e-3 for 1e-3 < lambda < 1e4."""
+    z = np.load(os.path.join(G, "lrt_panels.npz"))
+    lams = z["lams"]
+    for name in ["sig", "weak", "null", "c1"]:
+        d, Y, W, X = (z[f"{name}_{k}"] for k in "dYWX")
+        fn = z[f"{name}_ml_functions"]
+        for si, Wx in enumerate([W, np.c_[W, X[:, 0]], np.c_[W, X[:, 1]]]):
+            Wx = np.ascontiguousarray(Wx, np.float32)
+            for li, lam in enumerate(lams):
+                o = O.ml_functions(lam, d, Y, Wx)
+                if lam <= 400:
+                    assert abs(o[0] - fn[si, li, 0]) <= 3 * np.spacing(np.float32(abs(fn[si, li, 0]))), (name, si, lam)
+                elif lam <= 1e3:     # the reference's float32 inverse of W'H^-1 W starts to lose digits
+                    assert abs(o[0] / fn[si, li, 0] - 1) <= 2e-6, (name, si, lam)
+                if 1e-3 < lam < 1e4:
+                    assert abs(o[1] / fn[si, li, 1] - 1) <= 1e-3 and abs(o[2] / fn[si, li, 2] - 1) <= 2e-3, (name, si, lam, o, fn[si, li])
