@@ -2,25 +2,27 @@
 """bench.py — headline benchmark of the MI355X-native pyGEMMA hot path.
 
 Metric (BASELINE.json): SNPs/sec (whole node) at n=10,000, c=5; K-eigendecomposition wall-clock.
-Workload (BASELINE.json configs[2], the shape the metric is quoted on): synthetic n=10,000 individuals,
-c=5 covariates; one "step" = one batch of B SNPs per GPU through the per-SNP hot path with inputs resident in
-HBM: rotation X <- U'X (fp32 MFMA GEMM)  ->  REML lambda search (decade scan + Brent + Newton) ->
-beta/se/tau/Wald F -> p-value (all on device) [-> RCCL all-gather of the 32-byte result rows when N > 1].
+Workload (BASELINE.json configs[2], the shape the metric is quoted on): synthetic n=10,000 individuals, c=5 covariates,
+p=100,000 SNPs per GPU.  One "step" = ONE PASS OVER ALL p SNPs of the rank, in HBM-resident batches of B SNPs, through the
+per-SNP hot path:  rotation X <- U'X  ->  REML lambda search (decade scan + Brent + Newton) -> beta/se/tau/Wald F -> p-value,
+all on the device, then ONE RCCL all-gather of the rank's 32-byte result rows when N > 1 (gather once at the end).
 The one-time eigendecomposition of K is timed separately (`eigh_seconds`), as the metric asks.
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-           bench.py --gpus N --steps K --warmup W
+    python bench.py                              # 1 GPU
+    python bench.py --gpus N                     # spawns N ranks itself (one process per GPU), or run under any launcher:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
 
-One process per GPU; SNP batches are independent units (no data-path collective except the result gather):
-"scaling": "weak".  torch is imported only when WORLD_SIZE > 1 (rendezvous, barrier, MAX-reduce of the time,
-RCCL all-gather); the compute path is the C ABI in include/pygemma_hip.h.
+One process per GPU; SNP shards are independent (weak scaling: p per GPU fixed).  Rank 0 builds K (syrk on the device), runs
+the eigensolver once and broadcasts U, d and the rotated y/W over RCCL; every rank generates its own genotype shard.
+No PyTorch anywhere: rendezvous is pygemma_amd/dist.py (stdlib), collectives are the C ABI's pg_comm_* (librccl).
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,22 +31,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pygemma_amd import _lib, synth  # noqa: E402
-
 F32_MFMA_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU
-BF16_MFMA_PEAK_TF = 2500.0 # dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md)
+F16_MFMA_PEAK_TF = 2500.0  # dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md)
 F64_VALU_PEAK_TF = 78.6    # fp64 vector peak (= fp64 matrix peak on MI355X): 128 FLOP/clk/CU
 
 
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/*_summary.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE passes at this bench's shapes, gfx950 x2 fetch correction); None if absent."""
+    """(HBM-side bytes per launch of `kernel`, source file) from the newest committed rocprofv3 PMC summary (profiles/*_summary.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes at this bench's batch shape, gfx950 x2 fetch correction); (None, None) if absent."""
     try:
         import glob
-        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))[-1]
-        return json.load(open(f))["pmc"][kernel]["hbm_bytes_per_launch"]
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+            v = json.load(open(f)).get("pmc", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+            if v is not None:
+                return v, os.path.relpath(f, ROOT)
     except Exception:
-        return None
+        pass
+    return None, None
 
 
 def host_cores():
@@ -59,274 +62,364 @@ def host_cores():
     return n
 
 
+def cpu_model():
+    try:
+        return next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        return "unknown"
+
+
 def log(rank, *a):
     if rank == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def make_inputs(n, c, B, rank, p_k, null=False):
-    """Deterministic synthetic panel: standardised Binomial(2, maf) genotypes; K from an independent
-    SNP set; y = 0.2 g0 + G_K b + e (h2 = 0.5).  K/y/W are identical on every rank, the SNP batch is per rank."""
-    rng = np.random.default_rng(synth.SEED)
-    GK = synth.genotypes(rng, n, p_k)                                   # (n, p_k) float32
-    Wm = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, c - 1))], axis=1).astype(np.float32)
-    b = (rng.standard_normal(p_k) * np.sqrt(0.5 / p_k)).astype(np.float32)
-    rngx = np.random.default_rng(synth.SEED + 1000 + rank)
-    X = synth.genotypes(rngx, n, B)                                     # (n, B) float32
-    g0 = synth.genotypes(np.random.default_rng(synth.SEED + 1), n, 1)[:, 0]
-    y = 0.2 * g0 + GK @ b + rng.standard_normal(n).astype(np.float32) * np.sqrt(0.5)
-    if null:                                                            # SURVEY 8d: the second, pure-noise phenotype
-        y = rng.standard_normal(n).astype(np.float32)
-    return GK, Wm, y.astype(np.float32).reshape(-1, 1), X
+def geno_codes(rng, n, p, chunk=8192):
+    """Hard calls 0/1/2 ~ Binomial(2, maf_g), maf_g ~ U(0.05, 0.5) as int8, generated from two uniform byte planes
+    (fast: ~1 GB/s): code = [u1 < maf] + [u2 < maf]."""
+    out = np.empty((n, p), np.int8)
+    for s in range(0, p, chunk):
+        e = min(p, s + chunk)
+        thr = np.floor(rng.uniform(0.05, 0.5, e - s) * 256.0).astype(np.uint8)
+        u = rng.integers(0, 256, size=(2, n, e - s), dtype=np.uint8)
+        out[:, s:e] = (u[0] < thr).astype(np.int8) + (u[1] < thr).astype(np.int8)
+    return out
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N child processes (one per GPU) BEFORE anything touches HIP in this
+    process, hand them RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, pass rank 0's JSON line through, return the worst exit code."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PYGEMMA_RDZV_KEY=f"bench{os.getpid()}")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=10000)
     ap.add_argument("--c", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16384, help="SNPs per GPU per step")
+    ap.add_argument("--snps", type=int, default=100000, help="SNPs per GPU per step (configs[2]: p = 100,000)")
+    ap.add_argument("--batch", type=int, default=16384, help="SNPs per HBM-resident batch")
     ap.add_argument("--grid", type=int, default=0, help="1 = calc_lambda_restricted(grid=True) path")
     ap.add_argument("--cpu-sample", type=int, default=256, help="SNPs of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--null", type=int, default=0, help="1 = pure-noise phenotype (SURVEY 8d second phenotype) instead of the polygenic one")
+    ap.add_argument("--weak", type=int, default=0, help="1 = weak-signal phenotype (h2 = 0.02): drives Newton towards its iteration cap")
     ap.add_argument("--fp32-rotate", type=int, default=0, help="1 = force the fp32-MFMA rotation even for genotype-valued X")
+    ap.add_argument("--e2e", type=int, default=1, help="1 = after the timed region also run lmm.pygemma from host X (incl. H2D and eigh)")
+    ap.add_argument("--eigh-cache", default="", help="npz path: reuse U, d (and K-derived inputs) from a previous run instead of running "
+                                                     "the eigensolver (rocprofv3 --pmc passes on the per-SNP kernels)")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(spawn_ranks(a))        # nothing in this process has touched the GPU
+
+    from pygemma_amd import _lib, dist, synth
+    rank, world, local_rank = dist.env_rank()
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    n, c, B = a.n, a.c, a.batch
+        log(rank, f"note: --gpus {a.gpus} but WORLD_SIZE={world}; using the launcher's world size")
+    n, c, B, P = a.n, a.c, a.batch, a.snps
     L = _lib.load()
     if _lib.device_count() < 1:
         raise SystemExit("no GPU visible: the MI355X path has no CPU fallback")
+    if any(k in os.environ.get("LD_PRELOAD", "") for k in ("rocprofiler", "rocprof")) or "ROCPROFILER_REGISTER_FORCE_LOAD" in os.environ \
+            or any(k.startswith("ROCPROF") for k in os.environ):
+        # counter mode cannot track the ~3e4 un-synchronised dispatches of the tridiagonalisation (profiles/r02_pmc_abort_diagnosis.txt)
+        os.environ.setdefault("PG_SYEVD_PANEL_SYNC", "1")
 
-    torch = dist = None
-    stream_ptr = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
-        stream_ptr = torch.cuda.current_stream().cuda_stream
-    ctx = _lib.Context(local_rank, stream=stream_ptr)
+    ctx = _lib.Context(local_rank)
+    # PYGEMMA_BENCH_FORCE_COMM=1: form the (1-rank) communicator and run every collective on a single GPU too (rehearsal of the N > 1 path)
+    comm = dist.init(ctx) if (world > 1 or os.environ.get("PYGEMMA_BENCH_FORCE_COMM")) else None
     vp = C.c_void_p
-
-    # ---------------- inputs, resident in HBM before any timed region
-    t0 = time.time()
-    p_k = 2 * n
-    GK, Wm, y, X = make_inputs(n, c, B, rank, p_k, null=bool(a.null))
-    log(rank, f"synthetic inputs n={n} c={c} B={B} p_k={p_k}: {time.time() - t0:.1f} s (host)")
     ldx = (n + 63) // 64 * 64
-    dGK = ctx.to_device(GK)
-    dGt = ctx.alloc(p_k * ldx * 4)
-    dK = ctx.alloc(n * n * 4)
-    _lib.check(L.pg_transpose_dev(ctx.handle, n, p_k, dGK.ptr, p_k, dGt.ptr, ldx), "transpose")
-    _lib.check(L.pg_kinship_dev(ctx.handle, n, p_k, dGt.ptr, ldx, dK.ptr), "kinship")
-    ctx.sync()
-    dGK.free(); dGt.free()
-
-    # ---------------- H1: eigendecomposition, timed on its own (one-time cost)
-    dev, dU = ctx.alloc(n * 4), ctx.alloc(n * n * 4)
-    eigh_s = []
-    for _ in range(2):
-        t = time.time()
-        _lib.check(L.pg_syevd_dev(ctx.handle, n, dK.ptr, dev.ptr, dU.ptr, None, None), "pg_syevd_dev")   # synchronous
-        eigh_s.append(time.time() - t)
-    log(rank, f"syevd n={n}: {min(eigh_s):.3f} s")
-    dK.free()
-
-    # rotate [y | W] with the same kernel (lmm.py:245-246), re-lay out as (n x c) / (n)
     q = 1 + c
-    dYW = ctx.to_device(np.ascontiguousarray(np.concatenate([y, Wm], axis=1)))
-    dYWr = ctx.alloc(q * ldx * 4)
-    _lib.check(L.pg_rotate_dev(ctx.handle, n, q, dU.ptr, n, dYW.ptr, q, dYWr.ptr, ldx), "rotate yw")
-    ctx.sync()
-    YWr = dYWr.download((q, ldx), np.float32)[:, :n]
-    dy = ctx.to_device(np.ascontiguousarray(YWr[0]))
-    dW = ctx.to_device(np.ascontiguousarray(YWr[1:].T))
-    ldX = B
-    dX = ctx.to_device(X)
+
+    # ---------------- K, eigendecomposition, rotated y/W: rank 0 computes, everybody receives (RCCL broadcast)
+    dU, dev, dy, dW = ctx.alloc(n * n * 4), ctx.alloc(n * 4), ctx.alloc(n * 4), ctx.alloc(n * c * 4)
+    eigh_s, kin_s, Khost, yW = [], None, None, None
+    p_k = 2 * n
+    t0 = time.time()
+    rng = np.random.default_rng(synth.SEED)
+    if rank == 0:
+        cache = a.eigh_cache and os.path.exists(a.eigh_cache)
+        Wm = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, c - 1))], axis=1).astype(np.float32)
+        if cache:
+            z = np.load(a.eigh_cache)
+            assert z["U"].shape == (n, n) and z["yW"].shape == (n, q), "eigh cache is for another shape"
+            dU.upload(z["U"]); dev.upload(z["d"]); yW = z["yW"]
+            log(rank, f"eigenpairs from {a.eigh_cache} (eigensolver skipped)")
+        else:
+            GK8 = geno_codes(rng, n, p_k)                                        # raw hard calls; standardised on the device
+            b = (rng.standard_normal(p_k) * np.sqrt((0.02 if a.weak else 0.5) / p_k)).astype(np.float32)
+            GKf = GK8.astype(np.float32)
+            mu, sd = GKf.mean(0), GKf.std(0); sd[sd == 0] = 1
+            g0 = geno_codes(np.random.default_rng(synth.SEED + 1), n, 1)[:, 0].astype(np.float32)
+            g0 = (g0 - g0.mean()) / max(g0.std(), 1e-6)
+            yv = 0.2 * g0 * (0.0 if a.weak else 1.0) + ((GKf - mu) / sd) @ b + rng.standard_normal(n).astype(np.float32) * np.sqrt(0.98 if a.weak else 0.5)
+            if a.null:
+                yv = rng.standard_normal(n).astype(np.float32)
+            yW = np.ascontiguousarray(np.concatenate([yv.reshape(-1, 1).astype(np.float32), Wm], axis=1))
+            dG = ctx.to_device(GKf)
+            dK = ctx.alloc(n * n * 4)
+            ctx.sync(); t = time.time()
+            _lib.check(L.pg_kinship_geno_dev(ctx.handle, n, p_k, dG.ptr, p_k, 1, dK.ptr), "pg_kinship_geno_dev")   # N3: standardise + syrk
+            ctx.sync(); kin_s = time.time() - t
+            dG.free(); del GKf, GK8
+            for _ in range(2):
+                t = time.time()
+                _lib.check(L.pg_syevd_dev(ctx.handle, n, dK.ptr, dev.ptr, dU.ptr, None, None), "pg_syevd_dev")   # synchronous
+                eigh_s.append(time.time() - t)
+            log(rank, f"kinship syrk n={n} p_k={p_k}: {kin_s * 1e3:.1f} ms; syevd: {min(eigh_s):.3f} s")
+            Khost = dK.download((n, n), np.float32) if (a.e2e and world == 1) else None      # for the end-to-end leg (host inputs)
+            dK.free()
+            if a.eigh_cache:
+                np.savez(a.eigh_cache, U=dU.download((n, n), np.float32), d=dev.download((n,), np.float32), yW=yW)
+        # rotate [y | W] with the fp32 MFMA kernel (lmm.py:245-246), re-lay out as (n) / (n x c)
+        dYW = ctx.to_device(yW)
+        dYWr = ctx.alloc(q * ldx * 4)
+        _lib.check(L.pg_rotate_dev(ctx.handle, n, q, dU.ptr, n, dYW.ptr, q, dYWr.ptr, ldx), "rotate yw")
+        ctx.sync()
+        YWr = dYWr.download((q, ldx), np.float32)[:, :n]
+        dy.upload(np.ascontiguousarray(YWr[0])); dW.upload(np.ascontiguousarray(YWr[1:].T))
+        dYW.free(); dYWr.free()
+    t_bc = None
+    if comm is not None:
+        comm.barrier(); t = time.time()
+        for buf, nb in ((dU, n * n * 4), (dev, n * 4), (dy, n * 4), (dW, n * c * 4)):
+            comm.broadcast(buf.ptr, nb, 0)
+        comm.barrier(); t_bc = time.time() - t
+    log(rank, f"K + eigh + rotated y/W on rank 0{'' if t_bc is None else f', RCCL broadcast {t_bc * 1e3:.1f} ms'}: {time.time() - t0:.1f} s")
+
+    # ---------------- this rank's genotype shard, resident in HBM as float32 (n x P) before any timed region
+    t0 = time.time()
+    X8 = geno_codes(np.random.default_rng(synth.SEED + 1000 + rank), n, P)
+    dX8 = ctx.to_device(X8)
+    dX = ctx.alloc(n * P * 4)
+    _lib.check(L.pg_cast_i8_f32_dev(ctx.handle, n, P, dX8.ptr, 0, P, dX.ptr, P), "pg_cast_i8_f32_dev")   # reference layout (n, P) float32
+    ctx.sync(); dX8.free()
+    log(rank, f"genotype shard n={n} P={P} generated + resident: {time.time() - t0:.1f} s (host RNG)")
+    batches = [(s, min(P, s + B)) for s in range(0, P, B)]
     dXr = ctx.alloc(B * ldx * 4)
-    # rotation: genotype fast path (the synthetic panel is standardised hard calls, like every caller's input) unless forced off
     dprep = ctx.alloc(L.pg_geno_prep_bytes(n))
     dwork = ctx.alloc(L.pg_geno_work_bytes(n, B))
     _lib.check(L.pg_geno_prep_dev(ctx.handle, n, dU.ptr, n, dprep.ptr), "pg_geno_prep_dev")
-    geno_used = [0, 0]
-    if world > 1:
-        res_t = torch.empty(32 * B, dtype=torch.uint8, device="cuda")
-        all_t = torch.empty(32 * B * world, dtype=torch.uint8, device="cuda")
-        res_ptr = res_t.data_ptr()
-    else:
-        res_buf = ctx.alloc(32 * B)
-        res_ptr = res_buf.ptr
-    # result row block: [F (B f64) | p (B f64) | beta | se | tau | lambda (B f32 each)]
-    pF, pP = res_ptr, res_ptr + 8 * B
-    pb, ps, pt, pl = (res_ptr + 16 * B + 4 * B * k for k in range(4))
+    # result block of the rank: P rows of 32 bytes [F (P f64) | p (P f64) | beta | se | tau | lambda (P f32 each)]
+    res = ctx.alloc(32 * P)
+    allres = ctx.alloc(32 * P * world) if comm is not None else None
+    pF, pP = res.ptr, res.ptr + 8 * P
+    pb, ps, pt, pl = (res.ptr + 16 * P + 4 * P * k for k in range(4))
     dstats = ctx.alloc(16)
-    L.pg_memset(ctx.handle, dstats.ptr, 0, 16)
+    geno_used = [0, 0]
 
-    ev = []
+    ev_pool = []
     def new_event():
         e = vp()
         _lib.check(L.pg_event_create(ctx.handle, C.byref(e)), "event")
-        ev.append(e)
+        ev_pool.append(e)
         return e
 
-    def step(e0=None, e1=None, e2=None):
-        if e0: L.pg_event_record(ctx.handle, e0)
-        is_geno = C.c_int(0)
-        if not a.fp32_rotate:
-            _lib.check(L.pg_rotate_geno_dev(ctx.handle, n, B, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx, dwork.ptr, C.byref(is_geno)),
-                       "pg_rotate_geno_dev")
-        if not is_geno.value:
-            _lib.check(L.pg_rotate_dev(ctx.handle, n, B, dU.ptr, n, dX.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
-        geno_used[1 if is_geno.value else 0] += 1
-        if e1: L.pg_event_record(ctx.handle, e1)
-        _lib.check(L.pg_assoc_dev(ctx.handle, n, c, B, dev.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, a.grid,
-                                  pb, ps, pt, pl, pF, pP, dstats.ptr), "pg_assoc_dev")
-        if e2: L.pg_event_record(ctx.handle, e2)
-        if world > 1:
-            dist.all_gather_into_tensor(all_t, res_t)   # RCCL over xGMI: 32 B per SNP
+    def step(events=None, fp32=False):
+        for bi, (s, e) in enumerate(batches):
+            pbn = e - s
+            if events: L.pg_event_record(ctx.handle, events[bi][0])
+            is_geno = C.c_int(0)
+            if not fp32:
+                _lib.check(L.pg_rotate_geno_dev(ctx.handle, n, pbn, dprep.ptr, dX.ptr + 4 * s, P, dXr.ptr, ldx, dwork.ptr, C.byref(is_geno)),
+                           "pg_rotate_geno_dev")
+            if not is_geno.value:
+                _lib.check(L.pg_rotate_dev(ctx.handle, n, pbn, dU.ptr, n, dX.ptr + 4 * s, P, dXr.ptr, ldx), "pg_rotate_dev")
+            geno_used[1 if is_geno.value else 0] += 1
+            if events: L.pg_event_record(ctx.handle, events[bi][1])
+            _lib.check(L.pg_assoc_dev(ctx.handle, n, c, pbn, dev.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, a.grid,
+                                      pb + 4 * s, ps + 4 * s, pt + 4 * s, pl + 4 * s, pF + 8 * s, pP + 8 * s, dstats.ptr), "pg_assoc_dev")
+            if events: L.pg_event_record(ctx.handle, events[bi][2])
+        if comm is not None:
+            dist.gather_result_rows(comm, res.ptr, allres.ptr, P)      # RCCL over xGMI: 32 B per SNP, once per pass
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier()
         ctx.sync()
 
     for _ in range(a.warmup):
-        step()
+        step(fp32=bool(a.fp32_rotate))
     L.pg_memset(ctx.handle, dstats.ptr, 0, 16)
-    events = [(new_event(), new_event(), new_event()) for _ in range(a.steps)]
+    events = [[(new_event(), new_event(), new_event()) for _ in batches] for _ in range(a.steps)]
     barrier()
     t = time.perf_counter()
     for k in range(a.steps):
-        step(*events[k])
+        step(events[k], fp32=bool(a.fp32_rotate))
     barrier()
     elapsed = time.perf_counter() - t
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    if comm is not None:
+        elapsed = comm.allreduce_max(elapsed)
 
-    # per-kernel durations from the HIP events recorded on the launch stream
-    # one extra, untimed-by-the-metric launch of each rotation kernel alone for the per-kernel roofline legs
-    def time_call(fn):
-        ea, eb = new_event(), new_event()
-        L.pg_event_record(ctx.handle, ea); fn(); L.pg_event_record(ctx.handle, eb)
-        m = C.c_float(); L.pg_event_elapsed_ms(ctx.handle, ea, eb, C.byref(m)); return m.value * 1e-3
-    t_f32 = time_call(lambda: _lib.check(L.pg_rotate_dev(ctx.handle, n, B, dU.ptr, n, dX.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev"))
-    rot_ms, assoc_ms = [], []
+    # per-kernel durations of the FULL batches from the HIP events recorded on the launch stream
     ms = C.c_float()
-    for e0, e1, e2 in events:
-        L.pg_event_elapsed_ms(ctx.handle, e0, e1, C.byref(ms)); rot_ms.append(ms.value)
-        L.pg_event_elapsed_ms(ctx.handle, e1, e2, C.byref(ms)); assoc_ms.append(ms.value)
-    stats = dstats.download((2,), np.uint64).astype(np.float64) / (B * a.steps)
+    rot_ms, assoc_ms = [], []
+    for evs in events:
+        for bi, (s, e) in enumerate(batches):
+            if e - s != B:
+                continue
+            L.pg_event_elapsed_ms(ctx.handle, evs[bi][0], evs[bi][1], C.byref(ms)); rot_ms.append(ms.value)
+            L.pg_event_elapsed_ms(ctx.handle, evs[bi][1], evs[bi][2], C.byref(ms)); assoc_ms.append(ms.value)
+    stats = dstats.download((2,), np.uint64).astype(np.float64) / (P * a.steps)
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()                   # rank 0 finishes its report, then everybody tears the group down together
-            dist.destroy_process_group()
+        if comm is not None:
+            comm.barrier()                   # rank 0 finishes its report, then everybody tears the communicator down together
+            comm.close()
         return
 
-    # sanity on the last batch (never inside the timed region)
-    if world > 1:
-        host = all_t[: 32 * B].cpu().numpy()
-    else:
-        host = res_buf.download((32 * B,), np.uint8)
-    beta = host[16 * B: 20 * B].view(np.float32)
-    pv = host[8 * B: 16 * B].view(np.float64)
-    lam = host[28 * B: 32 * B].view(np.float32)
+    # ---------------- report (rank 0), never inside the timed region
+    def time_step(fp32):
+        ctx.sync(); tt = time.perf_counter(); step(fp32=fp32); ctx.sync(); return time.perf_counter() - tt
+    t_other = time_step(not a.fp32_rotate) if comm is None else None      # the other rotation path, one pass
+    host = (allres if comm is not None else res).download((32 * P,), np.uint8)
+    beta = host[16 * P: 20 * P].view(np.float32)
+    pv = host[8 * P: 16 * P].view(np.float64)
+    lam = host[28 * P: 32 * P].view(np.float32)
     assert np.isfinite(beta).all() and ((pv >= 0) & (pv <= 1)).all(), "non-finite results"
 
-    value = world * B * a.steps / elapsed
-    rot_avg = float(np.mean(rot_ms)) * 1e-3
-    assoc_avg = float(np.mean(assoc_ms)) * 1e-3
+    value = world * P * a.steps / elapsed
+    rot_avg, assoc_avg = float(np.mean(rot_ms)) * 1e-3, float(np.mean(assoc_ms)) * 1e-3
     rot_flops = 2.0 * n * n * B                       # algorithmic: 2 n^2 per SNP (SURVEY 8d stage R)
     m = c + 2
     # algorithmic fp64 flops of the assoc stage per SNP: decade scan 11 lambdas x 2 powers x m entries x 2n,
     # + per SNP-specific evaluation m(m+1)/2 entries x (2 | 3) powers x 2n
     assoc_flops_snp = 11 * 2 * m * 2.0 * n + (stats[0] * 2 + stats[1] * 3) * (m * (m + 1) / 2) * 2.0 * n
+    used_geno = geno_used[1] > 0 and not a.fp32_rotate
+    tr_rot, src_rot = pmc_traffic("rotate_geno_kernel" if used_geno else "rotate_kernel")
+    tr_as, src_as = pmc_traffic("assoc_kernel")
+    same_shape = (n, B, c) == (10000, 16384, 5)
     rl_rotate = ({"kernel": "rotate_geno_kernel (+detect/encode): fp16 MFMA 16x16x32, U split in 2 fp16 planes, fp32 accumulate",
-                  "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12, "peak": BF16_MFMA_PEAK_TF / 2.0, "unit": "TFLOP/s",
-                  "frac": rot_flops / rot_avg / 1e12 / (BF16_MFMA_PEAK_TF / 2.0),
+                  "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12, "peak": F16_MFMA_PEAK_TF / 2.0, "unit": "TFLOP/s",
+                  "frac": rot_flops / rot_avg / 1e12 / (F16_MFMA_PEAK_TF / 2.0),
                   "peak_note": "algorithmic 2n^2 flop/SNP against the dense fp16 MFMA peak (2500 TF) divided by the 2 fp16 passes a "
-                               "24-bit U needs; executed fp16 rate = 2x achieved",
-                  "traffic": pmc_traffic("rotate_geno_kernel") if (n, B) == (10000, 16384) else None,
-                  "algorithmic_bytes": 4.0 * n * B + 4.0 * n * n + 4.0 * ldx * B, "avg_launch_ms": rot_avg * 1e3}
-                 if geno_used[1] else
+                               "24-bit U needs; executed fp16 rate = 2x achieved"}
+                 if used_geno else
                  {"kernel": "rotate_kernel<4> (fp32 MFMA 32x32x2)", "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12,
-                  "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": rot_flops / rot_avg / 1e12 / F32_MFMA_PEAK_TF,
-                  "traffic": pmc_traffic("rotate_kernel") if (n, B) == (10000, 16384) else None,
-                  "algorithmic_bytes": 4.0 * n * B + 4.0 * n * n + 4.0 * ldx * B, "avg_launch_ms": rot_avg * 1e3})
-    rl_assoc = {"kernel": "assoc_kernel<%d> (+setup, p-values): fp64 VALU FMAs of the Gram passes, wave per SNP" % c, "bound": "mfma",
+                  "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": rot_flops / rot_avg / 1e12 / F32_MFMA_PEAK_TF})
+    rl_rotate.update({"traffic": tr_rot if same_shape else None, "traffic_source": src_rot if same_shape else None,
+                      "algorithmic_bytes": 4.0 * n * B + 4.0 * n * n + 4.0 * ldx * B, "avg_launch_ms": rot_avg * 1e3, "units_per_launch": B})
+    rl_assoc = {"kernel": "assoc_kernel<%d> (+setup, p-values): fp64 VALU FMAs of the Gram passes, wave per SNP" % c, "bound": "valu",
                 "achieved": assoc_flops_snp * B / assoc_avg / 1e12, "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
                 "frac": assoc_flops_snp * B / assoc_avg / 1e12 / F64_VALU_PEAK_TF,
                 "peak_note": "fp64 vector peak = fp64 matrix peak on MI355X (78.6 TF); only the Gram FMAs are counted (conversions, "
-                             "h*w products, reciprocals, reductions and sweeps are not): the VALU issue port is ~82 % busy (profiles/)",
-                "traffic": pmc_traffic("assoc_kernel") if (n, B, c) == (10000, 16384, 5) else None,
-                "algorithmic_bytes": (4.0 * ldx + 36) * B, "avg_launch_ms": assoc_avg * 1e3,
-                "hbm_GBps_algorithmic": (4.0 * n + 36) * B / assoc_avg / 1e9}
+                             "h*w products, reciprocals, reductions and sweeps are not)",
+                "traffic": tr_as if same_shape else None, "traffic_source": src_as if same_shape else None,
+                "algorithmic_bytes": (4.0 * ldx + 36) * B, "avg_launch_ms": assoc_avg * 1e3, "units_per_launch": B,
+                "flops_per_snp": assoc_flops_snp, "hbm_GBps_algorithmic": (4.0 * n + 36) * B / assoc_avg / 1e9}
+    rot_label = "f32 MFMA" if not used_geno else "f16x2->f32 MFMA (genotype codes exact; U in two fp16 planes)"
     out = {
         "metric": "SNPs/sec (whole node) at n=10,000 c=5; K-eigendecomp wallclock",
         "value": value, "unit": "SNPs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16x2->f32 (genotype rotation) | f32 (general rotation) + f64 (Gram/sweeps)", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[2]: synthetic n={n}, c={c}, {B} SNPs/GPU/step: rotate (U'X) + REML "
-                               f"{'grid' if a.grid else 'decade-scan+Brent+Newton'} + Wald F + p on device"
-                               + ("; RCCL all-gather of result rows" if world > 1 else ""),
-                   "n": n, "c": c, "snps_per_gpu_per_step": B, "lambda_path": "grid" if a.grid else "brent",
-                   "phenotype": "pure noise" if a.null else "polygenic h2=0.5 + one causal SNP",
+        "dtype": f"{rot_label} rotation + f64 Gram/sweeps (f32 rounding points of the reference)", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2]: synthetic n={n}, c={c}, p={P} SNPs per GPU per step in {len(batches)} HBM-resident batches of "
+                               f"<= {B}: rotate (U'X) + REML {'grid' if a.grid else 'decade-scan+Brent+Newton'} + Wald F + p on device"
+                               + ("; one RCCL all-gather of the result rows per step" if comm is not None else ""),
+                   "n": n, "c": c, "snps_per_gpu_per_step": P, "batch": B, "lambda_path": "grid" if a.grid else "brent",
+                   "phenotype": "pure noise" if a.null else ("weak signal h2=0.02" if a.weak else "polygenic h2=0.5 + one causal SNP"),
                    "parallelism": f"snp-shards x{world}"},
-        "eigh_seconds": min(eigh_s),
-        "eigh_note": "fp64 Householder tridiagonalisation + divide&conquer + back-transform on device, n=%d, one-time" % n,
+        "eigh_seconds": min(eigh_s) if eigh_s else None,
+        "eigh_note": "fp64 eigensolver on device, n=%d, one-time, on rank 0 only; U, d, rotated y/W broadcast over RCCL" % n,
+        "kinship_syrk_seconds": kin_s,
+        "rccl_broadcast_seconds": t_bc,
         # the dominant kernel of the step = the longer of the two launches
         "roofline": rl_assoc if assoc_avg >= rot_avg else rl_rotate,
         "roofline_rotate": rl_rotate,
         "roofline_assoc": rl_assoc,
-        "roofline_fp32_rotate": {"kernel": "rotate_kernel<4> (fp32 MFMA 32x32x2; the path for non-genotype X)", "bound": "mfma",
-                                 "achieved": rot_flops / t_f32 / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                                 "frac": rot_flops / t_f32 / 1e12 / F32_MFMA_PEAK_TF, "avg_launch_ms": t_f32 * 1e3,
-                                 "traffic": pmc_traffic("rotate_kernel") if (n, B) == (10000, 16384) else None},
-        "rotation_path": "genotype f16x2" if geno_used[1] else "fp32 MFMA",
+        "rotation_path": "fp32 MFMA (reference-arithmetic sgemm class)" if not used_geno else "genotype f16x2",
         "stage_snps_per_s_per_gpu": {"rotate": B / rot_avg, "assoc": B / assoc_avg},
         "evals_per_snp": {"fast": float(stats[0]), "newton": float(stats[1])},
         "lambda_median": float(np.median(lam)),
+        "cpu_model": cpu_model(),
     }
+    if t_other is not None:
+        key = "value_genotype_rotate" if a.fp32_rotate else "value_fp32_rotate"
+        out[key] = {"value": P / t_other, "unit": "SNPs/s", "ms_per_step": 1e3 * t_other,
+                    "note": ("same pass with the fp16x2 genotype rotation" if a.fp32_rotate else
+                             "same pass with the fp32-MFMA rotation forced (--fp32-rotate 1): the reference-arithmetic figure, bit-comparable "
+                             "to an fp32 fma chain; also the rate for X holding NaN/Inf") + "; one untimed-by-the-metric pass"}
 
-    # ---------------- CPU baseline: the oracle ("port"), bounded sample of the SAME workload, rank 0 / N=1 only
+    # ---------------- end to end through the public entry point, host inputs, H2D and eigh included (N = 1 only)
+    if a.e2e and world == 1 and Khost is not None:
+        try:
+            from pygemma_amd import lmm
+            dX_host = dX.download((n, P), np.float32)
+            Xp = lmm.pinned_empty((n, P), np.float32)
+            Xp[:] = dX_host
+            Yh, Wh = np.ascontiguousarray(yW[:, :1]), np.ascontiguousarray(yW[:, 1:])     # the un-rotated inputs rank 0 started from
+            e2e = {}
+            for tag, Xin in (("pinned_X", Xp), ("pageable_X", dX_host)):
+                st = {}
+                tt = time.perf_counter()
+                df = lmm.pygemma(Yh, Xin, Wh, Khost, stats=st)
+                dt = time.perf_counter() - tt
+                e2e[tag] = {"seconds": dt, "snps_per_s": P / dt, "snp_loop_seconds": st.get("seconds"), "snp_loop_snps_per_s": P / st["seconds"],
+                            "host_to_device_GBps_incl_compute": st["bytes_in"] / st["seconds"] / 1e9, "batches": st["batches"]}
+                assert np.isfinite(df["beta"].to_numpy()).all()
+            e2e["note"] = (f"lmm.pygemma(Y, X, W, K) from host float32 arrays, p={P}: K upload + eigh + rotation + scan + frame; snp_loop = the "
+                           "streamed SNP loop alone (H2D DMA of X included). PCIe-inclusive, never `value`.")
+            out["e2e"] = e2e
+            del Xp, dX_host
+        except Exception as ex:
+            out["e2e"] = {"error": repr(ex)}
+
+    # ---------------- CPU baseline: bounded sample of the SAME workload on the box's host cores, rank 0 / N=1 only.
+    # rotation = numpy @ (OpenBLAS sgemm: what the reference calls, lmm.py:244) when NumPy has a BLAS, else the oracle's fma chain;
+    # per-SNP path = the oracle ("port": C + OpenMP restatement, bit-validated against the reference in the build container).
     if a.cpu_sample > 0 and world == 1:
         try:
             from oracle import oracle as O
             S = min(a.cpu_sample, B)
             Uh = dU.download((n, n), np.float32)
             dh = dev.download((n,), np.float32)
-            Xs = np.ascontiguousarray(X[:, :S])
+            Xs = np.ascontiguousarray(dX.download((n, P), np.float32)[:, :S])
+            yr_h, Wr_h = dy.download((n,), np.float32), dW.download((n, c), np.float32)
             nthr = min(O.lib().orc_max_threads(), host_cores())
-            t = time.time()
-            Xrs = O.rotate(Uh, Xs, ldx=ldx)
-            t_rot = time.time() - t
-            t = time.time()
-            orc = O.calculate(dh, YWr[0], np.ascontiguousarray(YWr[1:].T), np.ascontiguousarray(Xrs[:, :n]), grid=bool(a.grid),
-                              order=0, nthreads=nthr, snp_major=True)
-            t_as = time.time() - t
-            same = float((orc["beta"].view(np.uint32) == beta[:S].view(np.uint32)).mean())
+            tt = time.time()
+            Xrs = np.ascontiguousarray((Uh.T @ Xs).T)                 # (S, n) SNP-major
+            t_rot = time.time() - tt
+            rot_kind = "numpy @ (BLAS sgemm)"
+            tt = time.time()
+            orc = O.calculate(dh, yr_h, Wr_h, Xrs, grid=bool(a.grid), order=0, nthreads=nthr, snp_major=True)
+            t_as = time.time() - tt
             rel = float(np.max(np.abs(orc["beta"].astype(np.float64) - beta[:S]) / orc["se_beta"].astype(np.float64)))
-            out["cpu_baseline"] = {"value": S / (t_rot + t_as), "unit": "SNPs/s", "cores": int(nthr), "kind": "port",
-                                   "sample": f"first {S} SNPs of the step batch: oracle rotate {t_rot:.2f} s + calculate {t_as:.2f} s "
-                                             f"(OpenMP, {nthr} threads); GPU vs oracle beta: {100 * same:.1f}% rows bit-identical, max |dbeta|/se {rel:.1e} "
-                                             f"(the oracle rotates with an fp32 fma chain; bit-identity is expected only with --fp32-rotate 1)"}
+            cb = {"value": S / (t_rot + t_as), "unit": "SNPs/s", "cores": int(nthr), "kind": "port", "cpu_model": cpu_model(),
+                  "sample": f"first {S} SNPs of the shard: rotation {rot_kind} {t_rot:.3f} s + oracle calculate {t_as:.2f} s (OpenMP, {nthr} threads); "
+                            f"GPU vs CPU beta: max |dbeta|/se {rel:.1e}",
+                  "per_snp_path_snps_per_s": S / t_as, "rotation_snps_per_s": S / t_rot}
+            try:
+                rt = json.load(open(os.path.join(ROOT, "profiles", "r02_reference_timing.json")))
+                cb["reference_timing_fixture"] = {
+                    "file": "profiles/r02_reference_timing.json",
+                    "note": "the REAL reference (Cython) timed in the build container on the same kind of slice (it cannot travel to the GPU box)",
+                    "where": rt["where"], "cpu_model": rt["cpu_model"], "cores": rt["cores"],
+                    "reference_brent_nproc8_snps_per_s": rt["per_snp_path"]["reference_brent_nproc8"]["snps_per_s"],
+                    "oracle_brent_threads8_snps_per_s": rt["per_snp_path"]["oracle_brent_threads8"]["snps_per_s"],
+                    "oracle_over_reference": rt["ratio_oracle8_over_reference8_brent"],
+                    "reference_eigh_float32_seconds": rt["eigh_float32"]["seconds"]}
+            except Exception:
+                pass
+            out["cpu_baseline"] = cb
         except Exception as ex:   # the baseline is a report, not a dependency of the measurement
-            out["cpu_baseline"] = {"value": None, "unit": "SNPs/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
+            out["cpu_baseline"] = {"value": None, "unit": "SNPs/s", "cores": 0, "kind": "port", "sample": f"failed: {ex!r}"}
     print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -13,8 +13,9 @@ tau as float32; lambda, F_wald, p_wald as float64; SNPs as object when `snps` is
 column blocks (lmm.py:427-434); results come back in block order = SNP order.
 
 Streaming (BASELINE configs 4-5): X never has to fit on a GPU.  Every GPU takes its block in batches; a batch is DMA'd
-from PINNED host memory (directly out of X when the caller allocated it with `pinned_empty`/`pin`, else through a pinned
-staging buffer filled by copy threads) on one stream while the previous batch computes on another, and its 32-byte
+from PINNED host memory (directly out of X: the caller's own pinned array — `pinned_empty`/`pin` — or X page-locked in place
+for the duration of the call; a pinned staging buffer filled by copy threads only where that fails) on one stream while the
+previous batch computes on another, and its 32-byte
 result rows come back through a pinned buffer.  With several GPUs the eigenvectors travel once, GPU 0 -> all, as one
 RCCL broadcast over xGMI (pg_comm_*; no PyTorch).
 There is no CPU fallback: without the HIP library or a GPU this raises.
@@ -129,6 +130,7 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
     try:
         L = _lib.load()
         ctx0 = comm.ctx if comm is not None else _lib.Context(device)
+        t_blk = time.time()
         try:
             ldx = (n + 63) // 64 * 64
             dd, dW, dy = ctx0.to_device(d), ctx0.to_device(Wr), ctx0.to_device(yr)
@@ -171,11 +173,14 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                 else:
                     todo.append((s, e))
             lock = threading.Lock()
+            if stats is not None:
+                stats["setup_s"] = max(stats.get("setup_s", 0.0), time.time() - t_blk)
 
             def worker():
                 try:
                     ctx = _lib.Context(device)
                     stg = None
+                    t_w = time.time()
                     try:
                         raw_bytes = pb_max * bpr if packed else n * ldX * esz
                         dX = ctx.alloc(raw_bytes)
@@ -185,6 +190,9 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                         dwork = ctx.alloc(L.pg_geno_work_bytes(n, pb_max)) if eigen else None
                         stg = _Staging(ctx, L, 0 if direct else raw_bytes, pb_max * nout)
                         hres = (C.c_char * (pb_max * nout)).from_address(stg.out)
+                        if stats is not None:
+                            with lock:
+                                stats["worker_alloc_s"] = max(stats.get("worker_alloc_s", 0.0), time.time() - t_w)
                         while True:
                             with lock:
                                 if not todo or errs:
@@ -476,7 +484,7 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
             out[col] = np.empty(p, np.float64)
     errs, threads = [], []
     if stats is not None:
-        stats.update({"batches": 0, "bytes_in": 0, "batch_s": 0.0, "pinned_input": bool((not packed) and _lib.is_pinned(X)), "gpus": ndev})
+        stats.update({"batches": 0, "bytes_in": 0, "batch_s": 0.0, "gpus": ndev})
     yr1 = np.ascontiguousarray(Yr.reshape(-1), np.float32)
     if checkpoint:
         os.makedirs(checkpoint, exist_ok=True)
@@ -497,7 +505,19 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
                 json.dump(key, f)
     t2 = time.time()
     comms = None
+    xpin = None
     try:
+        if not packed and not _lib.is_pinned(X):
+            # page-lock the caller's X in place for the duration of the scan (hipHostRegister: ~5 ms/GB measured, tools/bench_h2d.py)
+            # so that every batch is one 2-D DMA straight out of it; if the range cannot be registered (e.g. a read-only file
+            # mapping) the workers fall back to copy threads + a pinned staging buffer
+            try:
+                xpin = _lib.pin(X)
+            except _lib.PgError as ex:
+                _log(verbose, f"X could not be page-locked in place ({ex}); staging through pinned buffers")
+        if stats is not None:
+            stats["pinned_input"] = bool((not packed) and _lib.is_pinned(X))
+            stats["registered_in_place"] = xpin is not None
         if ndev > 1 and eigen:
             comms = _make_comms(L, ndev)      # RCCL communicator over the GPUs of this process: U goes GPU 0 -> all over xGMI
         for dev_id, (a, b) in enumerate(blocks):
@@ -509,6 +529,8 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
         for th in threads:
             th.join()
     finally:
+        if xpin is not None:
+            xpin.close()
         if comms:
             for cm in comms:
                 L.pg_comm_destroy(cm.handle)

@@ -55,3 +55,34 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     assert (got["lambda"] == ref["lambda"]).all()
     # and the reference's own rows for those SNPs
     assert (got["beta"].view(np.uint32) == z["brent_beta"][:37].view(np.uint32)).all()
+
+
+RDZV_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    from pygemma_amd import dist
+    rank, world, local = dist.env_rank()
+    uid = dist.exchange_id(rank, world, lambda: bytes(range(128)), timeout=60)
+    assert uid == bytes(range(128)) and len(uid) == 128, uid
+    a, b = dist.shard_range(1001, rank, world)
+    open(sys.argv[1] + f".{rank}", "w").write(f"{a} {b}")
+""")
+
+
+def test_rccl_id_rendezvous_two_processes_without_torch(tmp_path):
+    """The stdlib rendezvous of pygemma_amd/dist.py (what bench.py and any launcher use to hand the 128-byte RCCL id from rank 0
+    to the others): two processes with the launcher's environment variables, no torch, no GPU."""
+    script = tmp_path / "rdzv.py"
+    script.write_text(RDZV_WORKER % ROOT)
+    out = str(tmp_path / "done")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in (1, 0):          # rank 1 first: it has to wait for rank 0's file
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PYGEMMA_RDZV_KEY=f"test{os.getpid()}", PYGEMMA_RDZV_DIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, str(script), out], env=env))
+    assert [p.wait(timeout=120) for p in procs] == [0, 0]
+    assert open(out + ".0").read() == "0 501" and open(out + ".1").read() == "501 1001"
+    from pygemma_amd import dist
+    got = dist.unpack_block(np.arange(32 * 4, dtype=np.uint8).tobytes(), 4, 3)
+    assert got["beta"].shape == (3,) and got["F_wald"].dtype == np.float64

@@ -44,7 +44,13 @@ def test_streamed_batches_pinned_equals_pageable_equals_oracle(grid, monkeypatch
     st_a, st_b = {}, {}
     a = lmm.pygemma(rp["Y"], Xp, rp["W"], rp["d"], eigen=False, grid=grid, stats=st_a)
     b = lmm.pygemma(rp["Y"], rp["X"], rp["W"], rp["d"], eigen=False, grid=grid, stats=st_b)
-    assert st_a["pinned_input"] and not st_b["pinned_input"] and st_a["batches"] == 5 and st_b["batches"] == 5
+    assert st_a["pinned_input"] and not st_a["registered_in_place"] and st_b["registered_in_place"] and st_a["batches"] == 5 and st_b["batches"] == 5
+    monkeypatch.setattr(lmm._lib, "pin", lambda *a, **k: (_ for _ in ()).throw(lmm._lib.PgError("registration refused (test)")))
+    st_c = {}
+    cdf = lmm.pygemma(rp["Y"], rp["X"], rp["W"], rp["d"], eigen=False, grid=grid, stats=st_c)     # fallback: copy threads -> pinned staging
+    assert not st_c["pinned_input"] and st_c["batches"] == 5
+    for col in COLS:
+        assert (bits(cdf[col].to_numpy()) == bits(b[col].to_numpy())).all(), col
     orc = O.calculate(rp["d"], rp["Y"], rp["W"], rp["X"], grid=grid, order=1, nthreads=8)
     for col in COLS[:5]:
         assert (bits(a[col].to_numpy()) == bits(b[col].to_numpy())).all(), col
