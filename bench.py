@@ -219,7 +219,8 @@ def main():
     pF, pP = res.ptr, res.ptr + 8 * P
     pb, ps, pt, pl = (res.ptr + 16 * P + 4 * P * k for k in range(4))
     dstats = ctx.alloc(16)
-    geno_used = [0, 0]
+    dpath = ctx.alloc(4)
+    L.pg_memset(ctx.handle, dpath.ptr, 0, 4)
 
     ev_pool = []
     def new_event():
@@ -232,13 +233,11 @@ def main():
         for bi, (s, e) in enumerate(batches):
             pbn = e - s
             if events: L.pg_event_record(ctx.handle, events[bi][0])
-            is_geno = C.c_int(0)
-            if not fp32:
-                _lib.check(L.pg_rotate_geno_dev(ctx.handle, n, pbn, dprep.ptr, dX.ptr + 4 * s, P, dXr.ptr, ldx, dwork.ptr, C.byref(is_geno)),
-                           "pg_rotate_geno_dev")
-            if not is_geno.value:
+            if not fp32:     # path chosen on the device from the block's values (genotype codes -> fp16x2 MFMA); no host read-back
+                _lib.check(L.pg_rotate_auto_dev(ctx.handle, n, pbn, dU.ptr, n, dprep.ptr, dX.ptr + 4 * s, P, dXr.ptr, ldx, dwork.ptr,
+                                                dpath.ptr), "pg_rotate_auto_dev")
+            else:
                 _lib.check(L.pg_rotate_dev(ctx.handle, n, pbn, dU.ptr, n, dX.ptr + 4 * s, P, dXr.ptr, ldx), "pg_rotate_dev")
-            geno_used[1 if is_geno.value else 0] += 1
             if events: L.pg_event_record(ctx.handle, events[bi][1])
             _lib.check(L.pg_assoc_dev(ctx.handle, n, c, pbn, dev.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, a.grid,
                                       pb + 4 * s, ps + 4 * s, pt + 4 * s, pl + 4 * s, pF + 8 * s, pP + 8 * s, dstats.ptr), "pg_assoc_dev")
@@ -284,7 +283,27 @@ def main():
     # ---------------- report (rank 0), never inside the timed region
     def time_step(fp32):
         ctx.sync(); tt = time.perf_counter(); step(fp32=fp32); ctx.sync(); return time.perf_counter() - tt
+    used_path = int(dpath.download((1,), np.int32)[0])                    # before the other path's pass overwrites nothing: fp32 does not write it
     t_other = time_step(not a.fp32_rotate) if comm is None else None      # the other rotation path, one pass
+    # work-per-SNP tail: one more pass with the evaluation trace on
+    dtrace = ctx.alloc(4 * B)
+    tail = None
+    try:
+        _lib.check(L.pg_assoc_set_eval_trace(ctx.handle, dtrace.ptr), "trace on")
+        e0, e1 = new_event(), new_event()
+        s0, s1 = batches[0]
+        _lib.check(L.pg_rotate_dev(ctx.handle, n, s1 - s0, dU.ptr, n, dX.ptr, P, dXr.ptr, ldx), "pg_rotate_dev")
+        L.pg_event_record(ctx.handle, e0)
+        _lib.check(L.pg_assoc_dev(ctx.handle, n, c, s1 - s0, dev.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, a.grid, pb, ps, pt, pl, pF, pP, None), "pg_assoc_dev")
+        L.pg_event_record(ctx.handle, e1)
+        L.pg_event_elapsed_ms(ctx.handle, e0, e1, C.byref(ms))
+        tr = dtrace.download((s1 - s0,), np.uint32)
+        ev = (tr & 0xffff).astype(np.int64) + (tr >> 16).astype(np.int64)
+        tail = {"evals_per_snp_median": float(np.median(ev)), "evals_per_snp_p99": float(np.quantile(ev, 0.99)), "evals_per_snp_max": int(ev.max()),
+                "newton_max": int((tr >> 16).max()), "ms_per_launch_traced": float(ms.value), "snps": int(s1 - s0),
+                "note": "SNP-specific evaluations (Brent + Newton + final logL) per SNP on the first batch; the 11-point decade scan is extra and the same for every SNP"}
+    finally:
+        L.pg_assoc_set_eval_trace(ctx.handle, None)
     host = (allres if comm is not None else res).download((32 * P,), np.uint8)
     beta = host[16 * P: 20 * P].view(np.float32)
     pv = host[8 * P: 16 * P].view(np.float64)
@@ -298,7 +317,7 @@ def main():
     # algorithmic fp64 flops of the assoc stage per SNP: decade scan 11 lambdas x 2 powers x m entries x 2n,
     # + per SNP-specific evaluation m(m+1)/2 entries x (2 | 3) powers x 2n
     assoc_flops_snp = 11 * 2 * m * 2.0 * n + (stats[0] * 2 + stats[1] * 3) * (m * (m + 1) / 2) * 2.0 * n
-    used_geno = geno_used[1] > 0 and not a.fp32_rotate
+    used_geno = (not a.fp32_rotate) and used_path == 1
     tr_rot, src_rot = pmc_traffic("rotate_geno_kernel" if used_geno else "rotate_kernel")
     tr_as, src_as = pmc_traffic("assoc_kernel")
     same_shape = (n, B, c) == (10000, 16384, 5)
@@ -344,6 +363,7 @@ def main():
         "stage_snps_per_s_per_gpu": {"rotate": B / rot_avg, "assoc": B / assoc_avg},
         "evals_per_snp": {"fast": float(stats[0]), "newton": float(stats[1])},
         "lambda_median": float(np.median(lam)),
+        "work_tail": tail,
         "cpu_model": cpu_model(),
     }
     if t_other is not None:

@@ -125,6 +125,11 @@ int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const
                  const float *Xr, int64_t ldx, int grid, float *beta, float *se, float *tau, float *lambda,
                  double *F, double *pval, unsigned long long *stats_dev);
 
+/* Work-per-SNP trace (tail analysis of the data-dependent Brent/Newton path, pygemma_model.pyx:1349-1416): the following
+ * pg_assoc_dev calls on this context write, per SNP, fast evaluations | full (Newton) evaluations << 16 into trace_dev
+ * (device, >= p entries, caller-owned); NULL switches the trace off. */
+int pg_assoc_set_eval_trace(pg_ctx *ctx, unsigned *trace_dev);
+
 /* ---- N2: the same operator plus the likelihood-ratio test the reference sketches and leaves commented out
  * ("Fix these calculations later", lmm/lmm.py:137-141, 277-300), built from its own ML functions: lambda_alt =
  * calc_lambda(eigenVals, Y, [W, x]) (lmm/lmm.py:22-84: decade scan of dlogL/dlambda, brentq(rtol=0.1) + scipy newton),
@@ -183,6 +188,12 @@ size_t pg_geno_work_bytes(int64_t n, int64_t p);
 int pg_geno_prep_dev(pg_ctx *ctx, int64_t n, const float *U, int64_t ldU, void *Uprep);
 int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const float *X_n_by_p, int64_t ldX, float *Xr,
                        int64_t ldx, void *work, int *is_geno);
+/* pg_rotate_geno_dev + the caller's fallback to pg_rotate_dev in ONE enqueue, with the path chosen on the device: every candidate
+ * kernel is launched predicated on the flags of the detect pass, so the stream is never synchronised (the flag read-back of
+ * pg_rotate_geno_dev idles the GPU for ~0.7 ms per 16 384-SNP block at n = 10 000).  float32 X only.  U (row stride ldU) is the
+ * operand of the fp32-MFMA fallback; path_dev (device int, may be NULL) receives 1 / 2 / 0 like *is_geno. */
+int pg_rotate_auto_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU, const void *Uprep, const float *X_n_by_p, int64_t ldX,
+                       float *Xr, int64_t ldx, void *work, int *path_dev);
 /* The same for X stored as 8-bit integers (int8 / uint8 genotype matrices; the reference casts any dtype to float32,
  * lmm/lmm.py:121-122, so the values are identical): 4x fewer bytes to upload and to scan.  pg_cast_i8_f32_dev makes the
  * float32 image a block needs when it does not qualify (then pg_rotate_dev as usual). */

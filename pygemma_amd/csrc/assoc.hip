@@ -63,6 +63,7 @@ struct AssocParams {
     float *beta, *se, *tau, *lam;
     double *F;
     unsigned long long *stats;
+    unsigned *trace;       // optional: per SNP, fast evaluations | full (Newton) evaluations << 16 (pg_assoc_set_eval_trace)
     // N2 (LRT instantiations only): ML lambda and log-likelihood per SNP; ml_c = f32(f32((n/2) ln(n/2pi)) - (n/2)) (pyx:1552-1554)
     int lrt, nhalf;
     float ml_c;
@@ -887,6 +888,7 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
         const double t = (double)__fdiv_rn(b, sb);
         pr.beta[g] = b; pr.se[g] = sb; pr.tau[g] = ta; pr.lam[g] = best_lambda; pr.F[g] = t * t;
         if (pr.stats) { atomicAdd(&pr.stats[0], (unsigned long long)n_fast); atomicAdd(&pr.stats[1], (unsigned long long)n_full); }
+        if (pr.trace) pr.trace[g] = n_fast | (n_full << 16);
     }
 }
 
@@ -1301,6 +1303,7 @@ static int assoc_run(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, c
     pr.n_vals = ctx->plan.n_leaf + ctx->plan.n_node;
     pr.beta = beta; pr.se = se; pr.tau = tau; pr.lam = lambda; pr.F = F;
     pr.stats = stats_dev;
+    pr.trace = lrt ? nullptr : ctx->eval_trace;
 
     build_fixed_kernel<<<(pr.npad + 255) / 256, 256, 0, ctx->stream>>>(pr.n, pr.npad, c, (int)ldw, pr.rowf, d, Wr, yr, (float *)ctx->fixed);
     PG_HIP(hipGetLastError());
@@ -1322,6 +1325,16 @@ extern "C" int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const floa
     int rc = assoc_run(ctx, n, c, p, d, Wr, c, yr, Xr, ldx, grid, beta, se, tau, lambda, F, stats_dev, false, nullptr, nullptr);
     if (rc) return rc;
     if (pval) return pg_fdist_sf_dev(ctx, p, F, (double)(n - c - 1), pval);
+    return PG_OK;
+}
+
+// Work-per-SNP trace for tail analysis (the Brent/Newton path is data-dependent, pyx:1349-1416: up to 101 Newton iterations):
+// the next pg_assoc_dev calls of this context write, per SNP, fast evaluations | full evaluations << 16 into trace_dev
+// (>= p entries); NULL switches it off.
+extern "C" int pg_assoc_set_eval_trace(pg_ctx *ctx, unsigned *trace_dev)
+{
+    PG_REQUIRE(ctx, "pg_assoc_set_eval_trace: NULL ctx");
+    ctx->eval_trace = trace_dev;
     return PG_OK;
 }
 

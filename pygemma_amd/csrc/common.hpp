@@ -51,6 +51,7 @@ struct pg_ctx {
     void *fixed = nullptr; size_t fixed_bytes = 0;   // packed rows d,w..,y
     void *tabs = nullptr;  size_t tabs_bytes = 0;    // htab + fixed grams + ldH + t1
     unsigned long long *stats = nullptr;
+    unsigned *eval_trace = nullptr;                  // caller-owned (pg_assoc_set_eval_trace)
     pg::NpSumPlan plan;
     // generic scratch
     void *scratch = nullptr; size_t scratch_bytes = 0;

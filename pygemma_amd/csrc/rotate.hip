@@ -30,6 +30,7 @@ struct RotParams {
     float scale;
     int tiles_m, tiles_n;
     int lower;   // syrk mode (square output, X == U): only tiles on or below the diagonal are computed, the rest is mirrored
+    const int *cond;   // pg_rotate_auto_dev: run only if (cond[0] & 2), i.e. the block holds a NaN/Inf (nullptr: always)
 };
 
 template <int VEC>
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256, 2) void rotate_kernel(RotParams rp)
 {
     __shared__ float As[2][RBK][RBM];
     __shared__ float Bs[2][RBK][RBN];
+    if (rp.cond && !(rp.cond[0] & 2)) return;      // uniform over the grid
     // ---- XCD-aware, grouped tile order
     const int T = rp.lower ? rp.tiles_m * (rp.tiles_m + 1) / 2 : rp.tiles_m * rp.tiles_n;
     const int b = blockIdx.x;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void rotate_kernel(RotParams rp)
 using namespace pg;
 
 static int launch_tn(pg_ctx *ctx, long long kdim, long long ncol, long long p, const float *U, long long ldU, const float *X,
-                     long long ldX, float *out, long long ldx, float scale, bool lower = false)
+                     long long ldX, float *out, long long ldx, float scale, bool lower = false, const int *cond = nullptr)
 {
     static_assert(RBM == RBN, "the syrk tile enumeration assumes square tiles");
     RotParams rp{};
@@ -163,6 +165,7 @@ static int launch_tn(pg_ctx *ctx, long long kdim, long long ncol, long long p, c
     rp.tiles_m = (int)((p + RBM - 1) / RBM);
     rp.tiles_n = (int)((ncol + RBN - 1) / RBN);
     rp.lower = lower ? 1 : 0;
+    rp.cond = cond;
     const long long T = lower ? (long long)rp.tiles_m * (rp.tiles_m + 1) / 2 : (long long)rp.tiles_m * rp.tiles_n;
     PG_REQUIRE(T < (1LL << 31), "rotate: too many tiles; process SNPs in batches");
     const bool vec = (ldU % 4 == 0) && (ldX % 4 == 0) && (((uintptr_t)U | (uintptr_t)X) % 16 == 0);
@@ -171,6 +174,14 @@ static int launch_tn(pg_ctx *ctx, long long kdim, long long ncol, long long p, c
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
+
+namespace pg {
+int rotate_fp32_cond(pg_ctx *ctx, long long n, long long p, const float *U, long long ldU, const float *X, long long ldX, float *Xr,
+                     long long ldx, const int *cond, int)
+{
+    return launch_tn(ctx, n, n, p, U, ldU, X, ldX, Xr, ldx, 1.0f, false, cond);
+}
+}  // namespace pg
 
 extern "C" int pg_rotate_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU, const float *X, int64_t ldX,
                              float *Xr, int64_t ldx)

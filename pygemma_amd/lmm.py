@@ -234,12 +234,9 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                         _lib.check(L.pg_cast_i8_f32_dev(ctx.handle, n, pb, dX.ptr, int(X.dtype == np.uint8), ldX, dXf.ptr, ldX),
                                                    "pg_cast_i8_f32_dev")
                                         _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dXf.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
-                                elif eigen:
-                                    is_geno = C.c_int(0)
-                                    _lib.check(L.pg_rotate_geno_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx, dwork.ptr,
-                                                                    C.byref(is_geno)), "pg_rotate_geno_dev")
-                                    if not is_geno.value:
-                                        _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dX.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
+                                elif eigen:      # float32 block: path (genotype fp16x2 / split planes / fp32 MFMA) chosen on the device, no host wait
+                                    _lib.check(L.pg_rotate_auto_dev(ctx.handle, n, pb, dU.ptr, n, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx,
+                                                                    dwork.ptr, None), "pg_rotate_auto_dev")
                                 else:
                                     _lib.check(L.pg_transpose_dev(ctx.handle, n, pb, dX.ptr, ldX, dXr.ptr, ldx), "pg_transpose_dev")
                             # result block: [F | p | beta | se | tau | lambda] (+ [l_alt | l_null | D_lrt | p_lrt] f64 with lrt)

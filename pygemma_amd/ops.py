@@ -130,3 +130,29 @@ def rotate_geno(U, X, ctx=None, ldx=None):
     finally:
         if own:
             ctx.close()
+
+
+def rotate_auto(U, X, ctx=None):
+    """pg_rotate_auto_dev: the rotation of a float32 block with the path (genotype fp16x2 / split planes / fp32 MFMA for NaN
+    blocks) chosen on the device.  Returns (Xr (p, ldx) float32, path) with path 1 / 2 / 0 like pg_rotate_geno_dev's flag."""
+    L = _lib.load()
+    own = ctx is None
+    ctx = ctx or _lib.Context(0)
+    try:
+        U, X = _f32(U), _f32(X)
+        n, p = X.shape
+        ldx = (n + 63) // 64 * 64
+        dU, dX = ctx.to_device(U), ctx.to_device(X)
+        dprep, dwork = ctx.alloc(L.pg_geno_prep_bytes(n)), ctx.alloc(L.pg_geno_work_bytes(n, p))
+        dXr, dpath = ctx.alloc(p * ldx * 4), ctx.alloc(4)
+        _lib.check(L.pg_geno_prep_dev(ctx.handle, n, dU.ptr, n, dprep.ptr), "pg_geno_prep_dev")
+        _lib.check(L.pg_rotate_auto_dev(ctx.handle, n, p, dU.ptr, n, dprep.ptr, dX.ptr, p, dXr.ptr, ldx, dwork.ptr, dpath.ptr),
+                   "pg_rotate_auto_dev")
+        ctx.sync()
+        out = dXr.download((p, ldx), np.float32), int(dpath.download((1,), np.int32)[0])
+        for b in (dU, dX, dprep, dwork, dXr, dpath):
+            b.free()
+        return out
+    finally:
+        if own:
+            ctx.close()

@@ -111,3 +111,29 @@ def test_rotate_genotype_with_mean_imputed_missing(n, p, std, ctx):
     err_f = np.abs(f32p - exact) / bound
     assert err_g.max() <= 4 * 2.0 ** -24 * np.sqrt(n) and np.median(err_g) <= 2 * max(np.median(err_f), 1e-9)
     assert (got[:, n:] == 0).all()
+
+
+def test_rotate_auto_device_side_path_choice_equals_host_side(ctx):
+    """pg_rotate_auto_dev enqueues every candidate kernel predicated on the detect pass's flags (no host read-back): for each of
+    the four kinds of block it must produce exactly what pg_rotate_geno_dev + the caller's fallback produce, and report the path."""
+    from pygemma_amd import ops
+    rng = np.random.default_rng(17)
+    n, p = 321, 200
+    U = np.linalg.qr(rng.standard_normal((n, n)))[0].astype(np.float32)
+    geno = _geno(rng, n, p, True)
+    imputed = _geno(rng, n, p, False); imputed[rng.random((n, p)) < 0.02] = 0.7310585
+    for j in range(p):                                   # one other value per column: the column mean of its called genotypes
+        col = imputed[:, j]; col[col == np.float32(0.7310585)] = np.float32(col[col != np.float32(0.7310585)].mean())
+    dosage = rng.uniform(0, 2, (n, p)).astype(np.float32)
+    nanblk = geno.copy(); nanblk[4, 9] = np.nan
+    for X, want in ((geno, 1), (imputed, 1), (dosage, 2), (nanblk, 0)):
+        got, path = ops.rotate_auto(U, X, ctx=ctx)
+        assert path == want
+        ref, ok = ops.rotate_geno(U, X, ctx=ctx)
+        assert ok == want
+        if want == 0:
+            ref = ops.rotate(U, X, ctx=ctx)
+            same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+            assert same.all() and np.isnan(got[9, :n]).all() and np.isfinite(got[8, :n]).all()
+        else:
+            assert (got.view(np.uint32) == ref.view(np.uint32)).all()
