@@ -414,17 +414,17 @@ __device__ __forceinline__ void load_elem(const AssocParams &pr, const float *xr
 }
 // software pipeline with a ring of PFD register sets (compile-time slots: no register copies, no scratch)
 constexpr int PFD = PG_PFD;
-template <class E, class LoadF, class BodyF>
+template <class E, int PF = PFD, class LoadF, class BodyF>
 __device__ __forceinline__ void pipelined(int niter, LoadF &&ld, BodyF &&body)
 {
-    E buf[PFD];
+    E buf[PF];
 #pragma unroll
-    for (int d = 0; d < PFD; d++) ld(buf[d], d < niter ? d : niter - 1);
-    for (int it = 0; it < niter; it += PFD) {
+    for (int d = 0; d < PF; d++) ld(buf[d], d < niter ? d : niter - 1);
+    for (int it = 0; it < niter; it += PF) {
 #pragma unroll
-        for (int d = 0; d < PFD; d++) {
+        for (int d = 0; d < PF; d++) {
             if (it + d < niter) body(buf[d], it + d);
-            const int nx = it + d + PFD;
+            const int nx = it + d + PF;
             ld(buf[d], nx < niter ? nx : niter - 1);
         }
     }
@@ -504,7 +504,8 @@ __device__ __forceinline__ void gram_pass_slot(const AssocParams &pr, const floa
 #pragma unroll
     for (int k = 0; k < NVP; k++) acc[k] = 0.0;
     double s = 0.0;
-    pipelined<Elem<C>>(pr.niter, [&](Elem<C> &e, int it) { load_elem<C, HASX>(pr, xrow, it * 64 + lane, e); },
+    // wide rows (c > 20): one register set in flight instead of two, the element ring would push the slot's 64 accumulators to scratch
+    pipelined<Elem<C>, (M > 22 ? 1 : PFD)>(pr.niter, [&](Elem<C> &e, int it) { load_elem<C, HASX>(pr, xrow, it * 64 + lane, e); },
                        [&](const Elem<C> &cur, int it) {
         const int i = it * 64 + lane;
         float d, colf[M];

@@ -1,33 +1,35 @@
 #!/bin/bash
 # Collect the round's judged measurements on the GPU box (run through gpurun from the repo root):
-#   bench line, rocprofv3 kernel stats of the same bench command, PMC passes (one counter group per run) on the
-#   per-kernel drivers at the bench's shapes.  Outputs under gpurun_out/prof_${TAG}_final/ ; tools/summarize_prof.py condenses them.
-set -e -o pipefail
-TAG=${1:-r01}
+#   the bench line, rocprofv3 --kernel-trace --stats of the SAME bench command, and PMC passes (one counter group per run) ON bench.py
+#   ITSELF (the eigensolver is skipped in those through --eigh-cache: counter mode + its dispatch depth, profiles/r02_pmc_abort_diagnosis.txt;
+#   one pass also runs WITH the eigensolver under PG_SYEVD_PANEL_SYNC to show that bench.py is profilable end to end).
+# Outputs under gpurun_out/prof_${TAG}_final/ ; tools/summarize_prof.py condenses them into profiles/.
+set -o pipefail
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_${TAG}_final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout -k 10 400 python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python3 $ROOT/bench.py --steps 10 --warmup 2 --cpu-sample 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python3 $ROOT/bench.py --e2e 0 --cpu-sample 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || { echo "stats failed"; tail -5 $OUT/stats.err; exit 1; }
 echo "stats done"
-pass() {  # name counters... -- driver args
+CACHE=$OUT/eigh_cache.npz
+timeout -k 10 300 python3 $ROOT/bench.py --steps 1 --warmup 0 --e2e 0 --cpu-sample 0 --eigh-cache $CACHE > /dev/null 2> $OUT/cache.err || { echo "cache run failed"; exit 1; }
+pass() {  # name counters...
   local name=$1; shift
-  local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
-  rocprofv3 --kernel-trace --pmc "${ctr[@]}" --output-format csv -d $OUT/$name -o c -- python3 "$@" > $OUT/$name.log 2>&1
-  echo "$name done"
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o c -- python3 $ROOT/bench.py --steps 2 --warmup 1 --e2e 0 --cpu-sample 0 --eigh-cache $CACHE > $OUT/$name.json 2> $OUT/$name.log
+  local rc=$?
+  echo "$name rc=$rc"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timeout: stopping"; exit 1; fi
 }
-pass fetch_geno FETCH_SIZE -- $ROOT/tools/bench_rotate_geno.py 10000 16384
-pass write_geno WRITE_SIZE -- $ROOT/tools/bench_rotate_geno.py 10000 16384
-pass sq_geno SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -- $ROOT/tools/bench_rotate_geno.py 10000 16384
-pass fetch_assoc FETCH_SIZE -- $ROOT/tools/bench_assoc.py 10000 16384 5
-pass write_assoc WRITE_SIZE -- $ROOT/tools/bench_assoc.py 10000 16384 5
-pass sq_assoc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $ROOT/tools/bench_assoc.py 10000 16384 5
-pass fetch_rot FETCH_SIZE -- $ROOT/tools/bench_rotate.py 10000 16384
-pass write_rot WRITE_SIZE -- $ROOT/tools/bench_rotate.py 10000 16384
-pass sq_rot SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $ROOT/tools/bench_rotate.py 10000 16384
-pass sq_dgemm_panel SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $ROOT/tools/bench_dgemm.py 8192 8192 128 1
-pass sq_dgemm_big SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $ROOT/tools/bench_dgemm.py 8192 8192 8192
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass sq_valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+pass sq_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES
+# bench.py WITH the eigensolver under the counter mode (bench.py sets PG_SYEVD_PANEL_SYNC itself when it sees the profiler)
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_WAVES --output-format csv -d $OUT/pmc_full -o c -- python3 $ROOT/bench.py --steps 1 --warmup 0 --e2e 0 --cpu-sample 0 > $OUT/pmc_full.json 2> $OUT/pmc_full.log
+echo "pmc_full rc=$?"
+rm -f $CACHE
 find $OUT -name "*.db" -delete
-ls -R $OUT | head -60
+ls -la $OUT | head -40
