@@ -96,9 +96,28 @@ def spawn_ranks(a):
                    PYGEMMA_RDZV_KEY=f"bench{os.getpid()}")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # wait for all; if one rank dies, the others would sit in the communicator's rendezvous for ever: end them (exact PIDs)
     rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for pr in list(live):
+            r = pr.poll()
+            if r is None:
+                continue
+            live.remove(pr)
+            if r != 0:
+                rc = max(rc, abs(r))
+                for other in live:
+                    other.terminate()
+                t_end = time.time() + 10
+                for other in live:
+                    try:
+                        other.wait(timeout=max(0.1, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        other.kill()
+                live = []
+                break
     return rc
 
 

@@ -1018,10 +1018,15 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
         sym_from_lower_kernel<<<1, 256, 0, st>>>(1, 1, K, w.A);
         if (hipMemcpyAsync(hd.data(), w.A, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = PG_EHIP;
     } else {
-        PG_HIP(hipMemsetAsync(w.Vall, 0, (size_t)n * n * 8, st));
-        PG_HIP(hipMemsetAsync(w.tau, 0, (size_t)n * 8, st));
-        sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n0, n, K, w.A);
-        rc = sytrd_device(ctx, n, w);
+        // no early return from here on: every failure falls through to cleanup() (~8 n^2 doubles leaked on this path)
+        if (hipMemsetAsync(w.Vall, 0, (size_t)n * n * 8, st) != hipSuccess || hipMemsetAsync(w.tau, 0, (size_t)n * 8, st) != hipSuccess) {
+            set_error("pg_syevd_dev: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = PG_EHIP;
+        }
+        if (!rc) {
+            sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n0, n, K, w.A);
+            rc = sytrd_device(ctx, n, w);
+        }
         if (!rc) {
             if (hipMemcpyAsync(hd.data(), w.d, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(he.data(), w.e, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
