@@ -194,6 +194,8 @@ int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, con
  * operand of the fp32-MFMA fallback; path_dev (device int, may be NULL) receives 1 / 2 / 0 like *is_geno. */
 int pg_rotate_auto_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU, const void *Uprep, const float *X_n_by_p, int64_t ldX,
                        float *Xr, int64_t ldx, void *work, int *path_dev);
+int pg_rotate_auto_i8_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const void *X8_n_by_p, int is_unsigned, int64_t ldX,
+                          float *Xr, int64_t ldx, void *work, int *path_dev);   /* int8/uint8 X (always finite): genotype or split path */
 /* The same for X stored as 8-bit integers (int8 / uint8 genotype matrices; the reference casts any dtype to float32,
  * lmm/lmm.py:121-122, so the values are identical): 4x fewer bytes to upload and to scan.  pg_cast_i8_f32_dev makes the
  * float32 image a block needs when it does not qualify (then pg_rotate_dev as usual). */

@@ -22,6 +22,8 @@
 // see rotate_geno_kernel.
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace pg {
 
 // Device-side choice of the rotation path (pg_rotate_auto_dev): every candidate kernel of a block is enqueued and looks at the
@@ -619,11 +621,12 @@ int rotate_fp32_cond(pg_ctx *ctx, long long n, long long p, const float *U, long
 // pg_rotate_geno_dev followed by the caller's fallback to pg_rotate_dev, but nothing synchronises the stream (the flag read-back
 // of pg_rotate_geno_dev costs ~0.7 ms of idle GPU per 16 384-SNP block at n = 10 000).  path_dev (optional, device int) receives
 // 1 / 2 / 0 like *is_geno.
-extern "C" int pg_rotate_auto_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU, const void *Uprep, const float *X, int64_t ldX,
-                                  float *Xr, int64_t ldx, void *work, int *path_dev)
+template <class T>
+static int rotate_auto_any(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU, const void *Uprep, const T *X, int64_t ldX,
+                           float *Xr, int64_t ldx, void *work, int *path_dev)
 {
-    PG_REQUIRE(ctx && U && Uprep && X && Xr && work, "pg_rotate_auto_dev: NULL argument");
-    PG_REQUIRE(n > 0 && p > 0 && ldU >= n && ldX >= p && ldx >= n && ldx <= (n + 127) / 128 * 128, "pg_rotate_auto_dev: bad shape");
+    PG_REQUIRE(ctx && Uprep && X && Xr && work, "pg_rotate_auto_dev: NULL argument");
+    PG_REQUIRE(n > 0 && p > 0 && ldX >= p && ldx >= n && ldx <= (n + 127) / 128 * 128, "pg_rotate_auto_dev: bad shape");
     PG_HIP(hipSetDevice(ctx->device));
     const long long kt = (n + GBK - 1) / GBK, ldk = kt * GBK;
     const size_t plane = ((size_t)p * ldk * 2 + 255) & ~(size_t)255;
@@ -634,23 +637,38 @@ extern "C" int pg_rotate_auto_dev(pg_ctx *ctx, int64_t n, int64_t p, const float
     int *flag = other + p;
     PG_HIP(hipMemsetAsync(flag, 0, 8, ctx->stream));
     minmax_init_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, other);
-    minmax_geno_kernel<float><<<dim3((unsigned)((p + 63) / 64), (unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, flag);
-    encode_geno_kernel<float><<<dim3((unsigned)((p + 63) / 64), (unsigned)((ldk + 127) / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk, flag);
+    minmax_geno_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, flag);
+    encode_geno_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((ldk + 127) / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk, flag);
     params_geno_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, other, v0, dx, dlt);
     // genotype block with an imputed value: indicator plane; finite non-genotype block: X in two fp16 planes (overwrites Gt, Gi, params)
-    indicator_geno_kernel<float><<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk, flag);
-    split_x_kernel<float><<<dim3((unsigned)((p + 63) / 64), (unsigned)((ldk + 127) / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, Gt, Gi, ldk, flag);
+    indicator_geno_kernel<T><<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk, flag);
+    split_x_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((ldk + 127) / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, Gt, Gi, ldk, flag);
     params_split_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, v0, dx, dlt, flag);
     PG_HIP(hipGetLastError());
     int rc = launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, true, flag);
     if (rc) return rc;
-    rc = rotate_fp32_cond(ctx, n, p, U, ldU, X, ldX, Xr, ldx, flag, COND_FP32);      // NaN / Inf block: the reference's propagation
-    if (rc) return rc;
+    if constexpr (std::is_same<T, float>::value) {       // NaN / Inf block (float input only): the reference's propagation
+        PG_REQUIRE(U && ldU >= n, "pg_rotate_auto_dev: U is needed for the fp32 fallback");
+        rc = rotate_fp32_cond(ctx, n, p, U, ldU, X, ldX, Xr, ldx, flag, COND_FP32);
+        if (rc) return rc;
+    }
     if (path_dev) {
         path_code_kernel<<<1, 1, 0, ctx->stream>>>(flag, path_dev);
         PG_HIP(hipGetLastError());
     }
     return PG_OK;
+}
+extern "C" int pg_rotate_auto_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU, const void *Uprep, const float *X, int64_t ldX,
+                                  float *Xr, int64_t ldx, void *work, int *path_dev)
+{
+    return rotate_auto_any<float>(ctx, n, p, U, ldU, Uprep, X, ldX, Xr, ldx, work, path_dev);
+}
+// 8-bit X (always finite): genotype path or split planes, nothing else; no host read-back either
+extern "C" int pg_rotate_auto_i8_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const void *X8, int is_unsigned, int64_t ldX,
+                                     float *Xr, int64_t ldx, void *work, int *path_dev)
+{
+    return is_unsigned ? rotate_auto_any<unsigned char>(ctx, n, p, nullptr, 0, Uprep, (const unsigned char *)X8, ldX, Xr, ldx, work, path_dev)
+                       : rotate_auto_any<signed char>(ctx, n, p, nullptr, 0, Uprep, (const signed char *)X8, ldX, Xr, ldx, work, path_dev);
 }
 
 // The same for X held as 8-bit integers (genotype matrices are often stored that way; the reference casts any dtype to

@@ -225,15 +225,9 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                         dXf = dXf or ctx.alloc(n * ldX * 4)
                                         _lib.check(L.pg_cast_f64_f32_dev(ctx.handle, n, pb, dX.ptr, ldX, dXf.ptr, ldX), "pg_cast_f64_f32_dev")
                                         _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dXf.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
-                                elif x8:
-                                    is_geno = C.c_int(0)
-                                    _lib.check(L.pg_rotate_geno_i8_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, int(X.dtype == np.uint8), ldX,
-                                                                       dXr.ptr, ldx, dwork.ptr, C.byref(is_geno)), "pg_rotate_geno_i8_dev")
-                                    if not is_geno.value:
-                                        dXf = dXf or ctx.alloc(n * ldX * 4)
-                                        _lib.check(L.pg_cast_i8_f32_dev(ctx.handle, n, pb, dX.ptr, int(X.dtype == np.uint8), ldX, dXf.ptr, ldX),
-                                                   "pg_cast_i8_f32_dev")
-                                        _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dXf.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
+                                elif x8:         # 8-bit block (always finite): genotype codes or split planes, chosen on the device
+                                    _lib.check(L.pg_rotate_auto_i8_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, int(X.dtype == np.uint8), ldX,
+                                                                       dXr.ptr, ldx, dwork.ptr, None), "pg_rotate_auto_i8_dev")
                                 elif eigen:      # float32 block: path (genotype fp16x2 / split planes / fp32 MFMA) chosen on the device, no host wait
                                     _lib.check(L.pg_rotate_auto_dev(ctx.handle, n, pb, dU.ptr, n, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx,
                                                                     dwork.ptr, None), "pg_rotate_auto_dev")
