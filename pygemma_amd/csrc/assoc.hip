@@ -43,6 +43,9 @@ constexpr int WPB = 4;    // wavefronts (= SNPs) per workgroup
 #ifndef PG_SCAN_NV
 #define PG_SCAN_NV 96        // decade-scan accumulators per pass (x-entries of as many lambdas as fit)
 #endif
+#ifndef PG_SWEEP_LDS_MIN_SLOTS
+#define PG_SWEEP_LDS_MIN_SLOTS 3   // lanes owning this many Gram entries or more exchange the sweeps' pivot column through LDS
+#endif
 #ifndef PG_WAVES
 #define PG_WAVES 2          // waves per SIMD the register allocation is held to
 #endif
@@ -245,6 +248,7 @@ template <int C> struct Shape {
     // which fits 2 waves/SIMD at any c; below PG_CHUNK_MIN_NP all entries of one or more powers share a pass.
     static constexpr int slot_nv(int sl) { return (NP - 64 * sl) < 64 ? (NP - 64 * sl) : 64; }
     static constexpr bool CHUNKED = NP > PG_CHUNK_MIN_NP;
+    static constexpr bool SWEEP_LDS = SLOTS >= PG_SWEEP_LDS_MIN_SLOTS;   // pivot column of the sweeps through per-wave LDS (3 M doubles)
     // scan: decade lambdas handled per pass
     // (two reduce-scatters of <= 64 and <= 32 values; PG_SCAN_NV caps the per-pass accumulators: 2 VGPRs each
     // — measured: 96 is best for c >= 3, 64 for c <= 2 where one more lambda per pass starts to spill)
@@ -324,31 +328,58 @@ __device__ __forceinline__ double gather(const double (&X)[SLOTS], int es)
     return v;
 }
 
+__device__ __forceinline__ void wave_lds_sync();
+
 // The c_tot sweeps of precompute_mat (pyx:947-963 / :1007-1036) with the Gram entries spread over the lanes:
 // every lane updates the entry (r,c) it owns, fetching the pivot-column operands from their owners; arithmetic per
 // entry identical to oracle sweeps(order=1).  Scalars (traces, pivots) are wave-uniform.
 template <int C, bool FULL>
 __device__ __forceinline__ void lane_sweeps(double (&P)[Shape<C>::SLOTS], double (&Q)[Shape<C>::SLOTS], double (&R)[Shape<C>::SLOTS],
-                                            const Own<C> &own, double t1, double t2, int lane, EvalOut &o)
+                                            const Own<C> &own, double t1, double t2, int lane, EvalOut &o, double *piv)
 {
     constexpr int M = Shape<C>::M, NP = Shape<C>::NP, SLOTS = Shape<C>::SLOTS;
+    // With three or more slots per lane (c >= 14) the pivot column goes through the wave's LDS (piv: 3 M doubles) instead of
+    // lane shuffles: a shuffle-gather costs SLOTS permutes per operand, 6 SLOTS^2 per step — pure data movement either way.
+    constexpr bool VIA_LDS = Shape<C>::SWEEP_LDS;
     if (own.valid[0] && own.e[0] == 0) P[0] = dmaxf(P[0], PG_MINV);
     double trP = t1, trPP = t2, apiv = 1.0;
     for (int i = 1; i < M; i++) {
         const int q = i - 1, eqq = tri(q, q);
-        const double a = gather<SLOTS>(P, eqq), b = gather<SLOTS>(Q, eqq);
-        const double e = FULL ? gather<SLOTS>(R, eqq) : 0.0;
-        if (lane == q) apiv = a;
+        double a, b, e = 0.0;
         double ur[SLOTS], uc[SLOTS], vr[SLOTS], vc[SLOTS], wr[SLOTS], wc[SLOTS];
         bool act[SLOTS];
+        if constexpr (VIA_LDS) {
 #pragma unroll
-        for (int sl = 0; sl < SLOTS; sl++) {
-            act[sl] = own.valid[sl] && own.c[sl] >= i;       // r >= c >= i
-            const int er = act[sl] ? tri(own.r[sl], q) : 0, ec = act[sl] ? tri(own.c[sl], q) : 0;
-            ur[sl] = gather<SLOTS>(P, er); uc[sl] = gather<SLOTS>(P, ec);
-            vr[sl] = gather<SLOTS>(Q, er); vc[sl] = gather<SLOTS>(Q, ec);
-            if (FULL) { wr[sl] = gather<SLOTS>(R, er); wc[sl] = gather<SLOTS>(R, ec); }
+            for (int sl = 0; sl < SLOTS; sl++)
+                if (own.valid[sl] && own.c[sl] == q) {       // owners of column q publish it (replicas write the same value)
+                    piv[own.r[sl]] = P[sl]; piv[M + own.r[sl]] = Q[sl];
+                    if (FULL) piv[2 * M + own.r[sl]] = R[sl];
+                }
+            wave_lds_sync();
+            a = piv[q]; b = piv[M + q];
+            if (FULL) e = piv[2 * M + q];
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; sl++) {
+                act[sl] = own.valid[sl] && own.c[sl] >= i;
+                const int rr = act[sl] ? own.r[sl] : q, cc = act[sl] ? own.c[sl] : q;
+                ur[sl] = piv[rr]; uc[sl] = piv[cc];
+                vr[sl] = piv[M + rr]; vc[sl] = piv[M + cc];
+                if (FULL) { wr[sl] = piv[2 * M + rr]; wc[sl] = piv[2 * M + cc]; }
+            }
+            wave_lds_sync();                                  // all reads done before the next step's writes
+        } else {
+            a = gather<SLOTS>(P, eqq); b = gather<SLOTS>(Q, eqq);
+            e = FULL ? gather<SLOTS>(R, eqq) : 0.0;
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; sl++) {
+                act[sl] = own.valid[sl] && own.c[sl] >= i;       // r >= c >= i
+                const int er = act[sl] ? tri(own.r[sl], q) : 0, ec = act[sl] ? tri(own.c[sl], q) : 0;
+                ur[sl] = gather<SLOTS>(P, er); uc[sl] = gather<SLOTS>(P, ec);
+                vr[sl] = gather<SLOTS>(Q, er); vc[sl] = gather<SLOTS>(Q, ec);
+                if (FULL) { wr[sl] = gather<SLOTS>(R, er); wc[sl] = gather<SLOTS>(R, ec); }
+            }
         }
+        if (lane == q) apiv = a;
         const double a2 = a * a, ia = -1.0 / a, ba2 = b / a2;
         if (FULL) {
             const double ba = b / a;
@@ -543,7 +574,8 @@ __device__ __forceinline__ void slot_passes(const AssocParams &pr, const float *
 
 // Level-0 Grams at an arbitrary lambda, then the sweeps.
 template <int C, bool FULL>
-__device__ __forceinline__ void eval_specific(const AssocParams &pr, const float *xrow, float lam, int lane, const Own<C> &own, EvalOut &o)
+__device__ __forceinline__ void eval_specific(const AssocParams &pr, const float *xrow, float lam, int lane, const Own<C> &own, EvalOut &o,
+                                              double *piv)
 {
     constexpr int SLOTS = Shape<C>::SLOTS;
     double P[SLOTS], Q[SLOTS], R[SLOTS], t1 = 0.0, t2 = 0.0;
@@ -564,7 +596,7 @@ __device__ __forceinline__ void eval_specific(const AssocParams &pr, const float
         gram_pass<C, 2, true>(pr, xrow, lam, lane, nullptr, P, Q, R, t1, t2);
         if (FULL) gram_pass<C, 4, true>(pr, xrow, lam, lane, nullptr, P, Q, R, t1, t2);
     }
-    lane_sweeps<C, FULL>(P, Q, R, own, t1, t2, lane, o);
+    lane_sweeps<C, FULL>(P, Q, R, own, t1, t2, lane, o, piv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -758,8 +790,11 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
     const long long g = (long long)blockIdx.x * WPB + wave;
     if (g >= pr.p) return;  // whole wavefront leaves; no workgroup barrier is used anywhere in this kernel
     // per-wave LDS: xent[NLAM][2M] doubles | evs[NLAM] | d1s[NLAM] | lls[NLAM] | vals[n_vals]
-    const size_t per_wave = (size_t)NLAM * 2 * M * 8 + NLAM * sizeof(EvalOut) + 2 * NLAM * 4 + (size_t)pr.n_vals * 4;
+    constexpr size_t piv_bytes = Shape<C>::SWEEP_LDS ? (size_t)3 * M * 8 : 0;
+    const size_t per_wave = piv_bytes + (size_t)NLAM * 2 * M * 8 + NLAM * sizeof(EvalOut) + 2 * NLAM * 4 + (size_t)pr.n_vals * 4;
     unsigned char *base = smem + (size_t)wave * ((per_wave + 15) & ~(size_t)15);
+    double *piv = reinterpret_cast<double *>(base);          // pivot column exchange of the sweeps (c >= 14 only)
+    base += piv_bytes;
     double *xent = reinterpret_cast<double *>(base);
     EvalOut *evs = reinterpret_cast<EvalOut *>(base + (size_t)NLAM * 2 * M * 8);
     float *d1s = reinterpret_cast<float *>(evs + NLAM);
@@ -786,7 +821,7 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
             R[sl] = 0.0;
         }
         EvalOut e;
-        lane_sweeps<C, false>(P, Q, R, own, pr.t1tab[t], 0.0, lane, e);
+        lane_sweeps<C, false>(P, Q, R, own, pr.t1tab[t], 0.0, lane, e, piv);
         if (lane == 0) {
             evs[t] = e;
             d1s[t] = d1_f(pr, pr.lam11[t], e.yPy, e.yPPy, e.trP);
@@ -812,18 +847,18 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
                 [&](double x) -> double {
                     EvalOut e;
                     const float lf = (float)x;      // pyx:1631: np.float32_t lam
-                    eval_specific<C, false>(pr, xrow, lf, lane, own, e);
+                    eval_specific<C, false>(pr, xrow, lf, lane, own, e, piv);
                     n_fast++;
                     return (double)d1_f(pr, lf, e.yPy, e.yPPy, e.trP);
                 },
                 (double)l0, (double)l1, (double)f0, (double)f1);
             // newton (pyx:1349-1416), all f32
             const float lroot = newton_dev(pr, (float)root, l0, l1, [&](float lf, EvalOut &e) {
-                eval_specific<C, true>(pr, xrow, lf, lane, own, e);
+                eval_specific<C, true>(pr, xrow, lf, lane, own, e, piv);
                 n_full++;
             });
             EvalOut e;
-            eval_specific<C, false>(pr, xrow, lroot, lane, own, e);   // pyx:186
+            eval_specific<C, false>(pr, xrow, lroot, lane, own, e, piv);   // pyx:186
             n_fast++;
             const float ldH = device_logdet_H(pr, lroot, lane, vals);
             const float ll = logl_f(pr, e.yPy, ldH, e.ld);       // pyx:188
@@ -850,7 +885,7 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
                 [&](double x) -> double {
                     EvalOut e;
                     const float lf = (float)x;
-                    eval_specific<C, false>(pr, xrow, lf, lane, own, e);
+                    eval_specific<C, false>(pr, xrow, lf, lane, own, e, piv);
                     n_fast++;
                     return (double)ml_d1_f(pr, lf, e.yPy, e.yPPy, e.sh);
                 },
@@ -859,7 +894,7 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
             for (int itr = 0; itr < 10; itr++) {
                 EvalOut e;
                 const float lf = (float)p0;
-                eval_specific<C, true>(pr, xrow, lf, lane, own, e);
+                eval_specific<C, true>(pr, xrow, lf, lane, own, e, piv);
                 n_full++;
                 const float fval = ml_d1_f(pr, lf, e.yPy, e.yPPy, e.sh);
                 if (fval == 0.0f) { pn = p0; break; }
@@ -872,7 +907,7 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
             if (ml_l == ml_l) {
                 EvalOut e;
                 const float lf = (float)pn;
-                eval_specific<C, false>(pr, xrow, lf, lane, own, e);
+                eval_specific<C, false>(pr, xrow, lf, lane, own, e, piv);
                 n_fast++;
                 const float l = ml_logl_f(pr, e.yPy, device_logdet_H(pr, lf, lane, vals));
                 if (l != l || l > ml_l) { ml_l = l; ml_lam = lf; }
@@ -898,7 +933,8 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
 static size_t assoc_lds_bytes(int c, int n_vals)
 {
     const int M = c + 2;
-    size_t per_wave = (size_t)NLAM * 2 * M * 8 + NLAM * sizeof(EvalOut) + 2 * NLAM * 4 + (size_t)n_vals * 4;
+    const int NP = M * (M + 1) / 2;
+    size_t per_wave = ((NP + 63) / 64 >= PG_SWEEP_LDS_MIN_SLOTS ? (size_t)3 * M * 8 : 0) + (size_t)NLAM * 2 * M * 8 + NLAM * sizeof(EvalOut) + 2 * NLAM * 4 + (size_t)n_vals * 4;
     per_wave = (per_wave + 15) & ~(size_t)15;
     return per_wave * WPB;
 }

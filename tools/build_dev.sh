@@ -9,7 +9,8 @@ OUT=$ROOT/pygemma_amd/lib_dev; mkdir -p $OUT/obj
 FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -Wno-unused-variable -DPG_ONLY_C=$C $*"
 cd $ROOT/pygemma_amd/csrc
 for f in api assoc comm rotate rotate_geno syevd; do
-  if [ $f = assoc ] || [ ! -f $OUT/obj/$f.o ] || [ $f.hip -nt $OUT/obj/$f.o ]; then
+  # stale objects are dangerous here (a changed pg_ctx layout in common.hpp once made assoc.o and api.o disagree): rebuild on any header change
+  if [ $f = assoc ] || [ ! -f $OUT/obj/$f.o ] || [ $f.hip -nt $OUT/obj/$f.o ] || [ common.hpp -nt $OUT/obj/$f.o ] || [ dgemm.hpp -nt $OUT/obj/$f.o ] || [ ../../include/pygemma_hip.h -nt $OUT/obj/$f.o ]; then
     ( /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $OUT/obj/$f.o 2>&1 | grep -v "loop not unrolled" | grep -E "error|warning: var" || true ) &
   fi
 done
