@@ -427,8 +427,10 @@ __device__ __forceinline__ void lane_sweeps(double (&P)[Shape<C>::SLOTS], double
 }
 
 // One element's operands: the packed fixed row (d, w_0..w_{C-1}, y) as 16-byte vectors plus x_i.
-// Loads are unconditional (the x address is clamped, rows >= n are zero in the table) so that the
-// next element's loads can be issued before the current element's arithmetic.
+// Loads are unconditional so that the next element's loads can be issued before the current element's arithmetic, and no value
+// is selected afterwards: rows >= n of the table hold w = y = 0 and d = +inf, which makes h = 1/(lam d + 1) exactly 0 there
+// (x = inf takes the division fallback of hinv_f32: 1/inf = 0), so every product of a pad element is 0 whatever x is read
+// (the x index is clamped to n-1: a caller's row need not have a pad).
 template <int C> struct Elem {
     static constexpr int S4 = (C + 2 + 3) / 4;
     float4 row[S4];
@@ -440,7 +442,7 @@ __device__ __forceinline__ void load_elem(const AssocParams &pr, const float *xr
     const float4 *src = reinterpret_cast<const float4 *>(pr.fixed + (size_t)i * pr.rowf);
 #pragma unroll
     for (int k = 0; k < Elem<C>::S4; k++) e.row[k] = src[k];
-    const int ic = i < pr.n ? i : pr.n - 1;
+    const int ic = min(i, pr.n - 1);
     e.x = HASX ? xrow[ic] : 0.0f;
 }
 // software pipeline with a ring of PFD register sets (compile-time slots: no register copies, no scratch)
@@ -471,7 +473,7 @@ __device__ __forceinline__ void unpack_elem(const AssocParams &pr, const Elem<C>
     d = buf[0];
 #pragma unroll
     for (int j = 0; j < C; j++) col[j] = buf[1 + j];
-    col[C] = (i < pr.n) ? e.x : 0.0f;
+    col[C] = e.x;
     col[C + 1] = buf[C + 1];
 }
 
@@ -493,7 +495,7 @@ __device__ __forceinline__ void gram_pass(const AssocParams &pr, const float *xr
         const int i = it * 64 + lane;
         float d, colf[M];
         unpack_elem<C>(pr, cur, i, d, colf);
-        const float h = (i < pr.n) ? hinv_f32(lam, d) : 0.0f;
+        const float h = hinv_f32(lam, d);        // pad rows: d = +inf -> h = 0
         if (htab_out) htab_out[i] = h;
         const double hd = (double)h;
         double col[M], a[M];
@@ -541,7 +543,7 @@ __device__ __forceinline__ void gram_pass_slot(const AssocParams &pr, const floa
         const int i = it * 64 + lane;
         float d, colf[M];
         unpack_elem<C>(pr, cur, i, d, colf);
-        const float h = (i < pr.n) ? hinv_f32(lam, d) : 0.0f;
+        const float h = hinv_f32(lam, d);        // pad rows: d = +inf -> h = 0
         if (htab_out) htab_out[i] = h;
         const double hd = (double)h, h2 = hd * hd;
         double col[M], a[M], g[PW == 3 ? M : 1];
@@ -1072,6 +1074,7 @@ __global__ void build_fixed_kernel(int n, int npad, int c, int ldw, int rowf, co
     if (i >= npad) return;
     float *row = fixed + (size_t)i * rowf;
     for (int k = 0; k < rowf; k++) row[k] = 0.0f;
+    if (i >= n) row[0] = INFINITY;      // h = 1/(lam*inf + 1) = 0: pad elements contribute exact zeros without any select
     if (i < n) {
         row[0] = d[i];
         for (int j = 0; j < c; j++) row[1 + j] = Wr[(size_t)i * ldw + j];

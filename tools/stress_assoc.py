@@ -8,7 +8,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ctx = _lib.Context(0)
 tot = 0
 for it in range(40):
-    c = int(rng.integers(1, 21)); n = int(rng.integers(c + 3, 900)); p = int(rng.integers(1, 200)); grid = bool(it % 4 == 3)
+    c = int(rng.integers(1, 31)); n = int(rng.integers(c + 3, 900)); p = int(rng.integers(1, 200)); grid = bool(it % 4 == 3)
     rp = synth.fast_rotated_panel(n, p, c, seed=int(rng.integers(1 << 30)), null=bool(it % 5 == 4))
     d, X, Y, W = rp["d"], rp["X"], rp["Y"].reshape(-1), rp["W"]
     g = ops.assoc(d, W, Y, X, grid=grid, ctx=ctx)
