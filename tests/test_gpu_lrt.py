@@ -57,3 +57,22 @@ def test_lrt_grid_path_and_streamed_batches(monkeypatch):
     lw, ll = -np.log10(b["p_wald"].to_numpy()), -np.log10(b["p_lrt"].to_numpy())
     assert np.corrcoef(lw, ll)[0, 1] >= 0.99
     assert b["p_lrt"].to_numpy()[0] < 1e-3 and b["p_wald"].to_numpy()[0] < 1e-3     # the planted causal SNP
+
+
+@pytest.mark.parametrize("n,p,c", [(300, 40, 12), (257, 24, 17), (320, 16, 22)])
+def test_lrt_wide_covariate_counts_vs_oracle(n, p, c):
+    """The LRT instantiations for slot-chunked shapes (c >= 11) and the second translation unit (c >= 16), null model included
+    (c - 1 covariates + the last one as the SNP): GPU vs the oracle in kernel order."""
+    from oracle import oracle as O
+    from pygemma_amd import lmm, synth
+    rp = synth.rotated_panel(n, p, c, seed=n + c, h2=0.4)
+    df = lmm.pygemma(rp["Y"], rp["X"], rp["W"], rp["d"], eigen=False, lrt=True)
+    orc = O.calculate_lrt(rp["d"], rp["Y"], rp["W"], rp["X"], order=1, nthreads=8)
+    ulp = np.spacing(np.float32(abs(orc["l_null"])))
+    assert abs(df["l_null"].to_numpy()[0] - orc["l_null"]) <= ulp
+    assert np.abs(df["l_alt"].to_numpy() - orc["l_alt"]).max() <= ulp
+    assert (bits(df["l_alt"].to_numpy().astype(np.float32)) == bits(orc["l_alt"])).mean() >= 0.9
+    np.testing.assert_allclose(df["p_lrt"].to_numpy(), orc["p_lrt"], rtol=5e-3)
+    base = lmm.pygemma(rp["Y"], rp["X"], rp["W"], rp["d"], eigen=False)
+    for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
+        assert (bits(df[col].to_numpy()) == bits(base[col].to_numpy())).all(), col
