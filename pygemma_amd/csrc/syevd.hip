@@ -28,6 +28,9 @@
 namespace pg {
 
 constexpr int NB = 64;  // reflectors per panel
+#ifndef PG_SYMV_OCC
+#define PG_SYMV_OCC 2     // workgroups of the symmetric symv per CU the register allocation is held to (A/B knob)
+#endif
 static int alloc_d(double **p, size_t count);
 
 // ---------------------------------------------------------------------------------------------
@@ -204,7 +207,7 @@ __device__ __forceinline__ double symv_half(int n, int rbase, int c0, bool cok, 
     return tot;
 }
 
-__global__ __launch_bounds__(256) void symv_sym_kernel(int n, int i, int ci, int nbr, const double *A, const double *P, const double *acol,
+__global__ __launch_bounds__(256, PG_SYMV_OCC) void symv_sym_kernel(int n, int i, int ci, int nbr, const double *A, const double *P, const double *acol,
                                                        const double *normpart, int nblk_col, double *hh, double *dvec, double *evec, double *tauvec,
                                                        double *rowpart, double *colpart, double *t)
 {
