@@ -225,7 +225,7 @@ def main():
     dX8 = ctx.to_device(X8)
     dX = ctx.alloc(n * P * 4)
     _lib.check(L.pg_cast_i8_f32_dev(ctx.handle, n, P, dX8.ptr, 0, P, dX.ptr, P), "pg_cast_i8_f32_dev")   # reference layout (n, P) float32
-    ctx.sync(); dX8.free()
+    ctx.sync()      # dX8 stays: the int8-resident leg of the report rotates straight from it
     log(rank, f"genotype shard n={n} P={P} generated + resident: {time.time() - t0:.1f} s (host RNG)")
     batches = [(s, min(P, s + B)) for s in range(0, P, B)]
     dXr = ctx.alloc(B * ldx * 4)
@@ -248,11 +248,14 @@ def main():
         ev_pool.append(e)
         return e
 
-    def step(events=None, fp32=False):
+    def step(events=None, fp32=False, int8=False):
         for bi, (s, e) in enumerate(batches):
             pbn = e - s
             if events: L.pg_event_record(ctx.handle, events[bi][0])
-            if not fp32:     # path chosen on the device from the block's values (genotype codes -> fp16x2 MFMA); no host read-back
+            if int8:         # the same genotypes as the int8 matrix a caller may hand over (lmm.pygemma takes it as it is): 4x fewer bytes to scan
+                _lib.check(L.pg_rotate_auto_i8_dev(ctx.handle, n, pbn, dprep.ptr, dX8.ptr + s, 0, P, dXr.ptr, ldx, dwork.ptr, None),
+                           "pg_rotate_auto_i8_dev")
+            elif not fp32:   # path chosen on the device from the block's values (genotype codes -> fp16x2 MFMA); no host read-back
                 _lib.check(L.pg_rotate_auto_dev(ctx.handle, n, pbn, dU.ptr, n, dprep.ptr, dX.ptr + 4 * s, P, dXr.ptr, ldx, dwork.ptr,
                                                 dpath.ptr), "pg_rotate_auto_dev")
             else:
@@ -304,6 +307,9 @@ def main():
         ctx.sync(); tt = time.perf_counter(); step(fp32=fp32); ctx.sync(); return time.perf_counter() - tt
     used_path = int(dpath.download((1,), np.int32)[0])                    # before the other path's pass overwrites nothing: fp32 does not write it
     t_other = time_step(not a.fp32_rotate) if comm is None else None      # the other rotation path, one pass
+    t_int8 = None
+    if comm is None:
+        step(int8=True); ctx.sync(); tt = time.perf_counter(); step(int8=True); ctx.sync(); t_int8 = time.perf_counter() - tt
     # work-per-SNP tail: one more pass with the evaluation trace on
     dtrace = ctx.alloc(4 * B)
     tail = None
@@ -392,6 +398,10 @@ def main():
                              "same pass with the fp32-MFMA rotation forced (--fp32-rotate 1): the reference-arithmetic figure, bit-comparable "
                              "to an fp32 fma chain; also the rate for X holding NaN/Inf") + "; one untimed-by-the-metric pass"}
 
+    if t_int8 is not None:
+        out["value_int8_X"] = {"value": P / t_int8, "unit": "SNPs/s", "ms_per_step": 1e3 * t_int8,
+                               "note": "same pass with X resident as the int8 genotype matrix (a dtype lmm.pygemma accepts as it is, lmm/lmm.py:121-122 "
+                                       "casts any dtype): detect/encode scan 1 byte per genotype; one untimed-by-the-metric pass"}
     # ---------------- end to end through the public entry point, host inputs, H2D and eigh included (N = 1 only)
     if a.e2e and world == 1 and Khost is not None:
         try:
