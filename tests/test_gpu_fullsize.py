@@ -89,3 +89,65 @@ def test_syevd_n4096_invariants(ctx):
     assert np.linalg.norm(K64 - (U * ev) @ U.T) / np.linalg.norm(K64) <= 1e-12 * np.sqrt(n)
     assert np.abs(np.sort(ev) - ev).max() == 0 and (ev32 >= 0).all()
     assert abs(ev.sum() - np.trace(K64)) <= 1e-10 * np.trace(K64)
+
+
+def test_syevd_n10000_sampled_invariants(ctx):
+    """The metric's eigendecomposition size: residual |K v - lambda v| on sampled eigenpairs, orthonormality of a sampled set,
+    trace, ordering, clamp — all from the float64 outputs (Tier B), without an O(n^3) host solve."""
+    from pygemma_amd import ops, synth
+    n = 10000
+    rng = np.random.default_rng(10)
+    G = synth.genotypes(rng, n, 2 * n)
+    K = (G @ G.T / (2 * n)).astype(np.float32)
+    del G
+    ev32, U32, ev, U = ops.syevd(K, ctx=ctx, want64=True)
+    K64 = np.tril(K).astype(np.float64); K64 = K64 + np.tril(K64, -1).T
+    idx = np.concatenate([[0, 1, 2, n - 3, n - 2, n - 1], rng.choice(n, 58, replace=False)])
+    V = U[:, idx]
+    res = np.abs(K64 @ V - V * ev[idx][None, :]).max() / np.abs(ev).max()
+    assert res <= 1e-12, res
+    sub = U[:, rng.choice(n, 256, replace=False)]
+    assert np.abs(sub.T @ sub - np.eye(256)).max() <= 1e-12
+    assert abs(ev.sum() - np.trace(K64)) <= 1e-10 * np.trace(K64)
+    assert (np.diff(ev) >= 0).all() and (ev32 >= 0).all() and ev32.dtype == np.float32
+    assert np.abs(U32.astype(np.float64) - U).max() <= 2.0 ** -24
+
+
+def test_kinship_n10000_sampled_entries_vs_float64():
+    """N3 at the metric's size: K = Z Z'/p with p = 20 000 raw hard calls standardised on the device; sampled rows against float64."""
+    from pygemma_amd import lmm
+    n, p = 10000, 20000
+    rng = np.random.default_rng(11)
+    G = rng.binomial(2, rng.uniform(0.05, 0.5, p), size=(n, p)).astype(np.float32)
+    K = lmm.kinship(G)
+    assert (K.view(np.uint32) == K.T.copy().view(np.uint32)).all()
+    G64 = G.astype(np.float64)
+    sd = G64.std(0); sd[sd == 0] = 1
+    Z = (G64 - G64.mean(0)) / sd
+    rows = rng.choice(n, 6, replace=False)
+    ref = Z[rows] @ Z.T / p
+    assert np.abs(K[rows] - ref).max() <= 1e-6 + 6e-8 * np.sqrt(p)
+
+
+def test_lrt_bench_shape_sample_vs_oracle(ctx):
+    """N2 at n = 10 000, c = 5: the LRT columns of a 24-SNP sample against the oracle in kernel order."""
+    import ctypes as C
+    from oracle import oracle as O
+    from pygemma_amd import _lib, synth
+    n, p, c = 10000, 24, 5
+    rp = synth.fast_rotated_panel(n, p, c, seed=99)
+    L = _lib.load()
+    ldx = (n + 63) // 64 * 64
+    Xr = np.zeros((p, ldx), np.float32); Xr[:, :n] = rp["X"].T
+    dd, dW, dy, dX = ctx.to_device(rp["d"]), ctx.to_device(rp["W"]), ctx.to_device(rp["Y"]), ctx.to_device(Xr)
+    o4, o8 = ctx.alloc(16 * p), ctx.alloc(48 * p)
+    _lib.check(L.pg_assoc_lrt_dev(ctx.handle, n, c, p, dd.ptr, dW.ptr, dy.ptr, dX.ptr, ldx, 0, o4.ptr, o4.ptr + 4 * p, o4.ptr + 8 * p, o4.ptr + 12 * p,
+                                  o8.ptr, o8.ptr + 8 * p, o8.ptr + 16 * p, o8.ptr + 24 * p, o8.ptr + 32 * p, o8.ptr + 40 * p), "pg_assoc_lrt_dev")
+    ctx.sync()
+    cols = o8.download((6, p), np.float64)          # F, p_wald, l_alt, l_null, D_lrt, p_lrt
+    orc = O.calculate_lrt(rp["d"], rp["Y"], rp["W"], rp["X"], order=1, nthreads=16)
+    ulp = np.spacing(np.float32(abs(orc["l_null"])))
+    assert abs(cols[3][0] - orc["l_null"]) <= ulp and np.abs(cols[2] - orc["l_alt"]).max() <= ulp
+    np.testing.assert_allclose(cols[5], orc["p_lrt"], rtol=5e-3)
+    wald = O.calculate(rp["d"], rp["Y"], rp["W"], rp["X"], grid=False, order=1, nthreads=16)
+    assert (bits(o4.download((4, p), np.float32)[0]) == bits(wald["beta"])).all()
