@@ -123,7 +123,7 @@ int build_npsum_plan(pg_ctx *ctx, int64_t n)
 using namespace pg;
 
 extern "C" const char *pg_last_error(void) { return g_err; }
-extern "C" const char *pg_version(void) { return "pygemma_hip 0.1.0 (gfx950)"; }
+extern "C" const char *pg_version(void) { return "pygemma_hip 0.2.0 (gfx950)"; }
 
 extern "C" int pg_device_count(void)
 {
