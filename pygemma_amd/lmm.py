@@ -133,17 +133,17 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
         t_blk = time.time()
         try:
             ldx = (n + 63) // 64 * 64
-            dd, dW, dy = ctx0.to_device(d), ctx0.to_device(Wr), ctx0.to_device(yr)
             dprep = None
+            if eigen and comm is not None:
+                # U: resident on GPU 0 (the eigensolver's output); the other GPUs get it over xGMI.  The collective comes before
+                # anything else of this thread that can fail (its receive buffer was allocated by the caller), so that no GPU is
+                # left waiting in the broadcast for a peer that has already given up.
+                t0 = time.time()
+                _lib.check(L.pg_comm_broadcast_dev(comm.handle, dU.ptr, n * n * 4, 0), "pg_comm_broadcast_dev")
+                ctx0.sync()
+                _log(verbose, f"GPU {device}: U ({n * n * 4 / 1e9:.2f} GB) broadcast over RCCL in {time.time() - t0:.3f} s")
+            dd, dW, dy = ctx0.to_device(d), ctx0.to_device(Wr), ctx0.to_device(yr)
             if eigen:
-                # U: already resident (GPU 0 keeps the eigensolver's output); the other GPUs get it over xGMI
-                if comm is not None:
-                    t0 = time.time()
-                    if dU is None:
-                        dU = ctx0.alloc(n * n * 4)
-                    _lib.check(L.pg_comm_broadcast_dev(comm.handle, dU.ptr, n * n * 4, 0), "pg_comm_broadcast_dev")
-                    ctx0.sync()
-                    _log(verbose, f"GPU {device}: U ({n * n * 4 / 1e9:.2f} GB) broadcast over RCCL in {time.time() - t0:.3f} s")
                 # genotype fast path of the rotation (<= 3 equally spaced values per column), fp32 MFMA otherwise
                 dprep = ctx0.alloc(L.pg_geno_prep_bytes(n))
                 _lib.check(L.pg_geno_prep_dev(ctx0.handle, n, dU.ptr, n, dprep.ptr), "pg_geno_prep_dev")
@@ -509,11 +509,14 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
         if stats is not None:
             stats["pinned_input"] = bool((not packed) and _lib.is_pinned(X))
             stats["registered_in_place"] = xpin is not None
+        dUs = [dU0] + [None] * (ndev - 1)
         if ndev > 1 and eigen:
             comms = _make_comms(L, ndev)      # RCCL communicator over the GPUs of this process: U goes GPU 0 -> all over xGMI
+            for g in range(1, ndev):          # receive buffers made here: an allocation failure surfaces before any thread waits in the collective
+                dUs[g] = comms[g].ctx.alloc(n * n * 4)
         for dev_id, (a, b) in enumerate(blocks):
             th = threading.Thread(target=_run_block, args=(dev_id, a, b, n, c, eigenVals, Wr, yr1, X,
-                                                           dU0 if dev_id == 0 else None, comms[dev_id] if comms else None,
+                                                           dUs[dev_id], comms[dev_id] if comms else None,
                                                            grid, eigen, lrt, out, errs, verbose, checkpoint, stats))
             th.start()
             threads.append(th)
