@@ -350,6 +350,9 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 // refill), the EARLY waves stage the genotype tile (4 per wave and stage), each group with its own counted wait.
 //   phase 2t   : early mem(t)   [A half of tile T+1|T+2; reads] | late mfma(t-1) [rolling reads of B[(t-1)%3]]
 //   phase 2t+1 : early mfma(t)                                  | late mem(t)    [B(t+2) -> B[(t-1)%3]; reads]
+#ifndef PG_GENO_GRP
+#define PG_GENO_GRP 4
+#endif
 __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 {
     if (!run_cond(gp.cond, gp.cmode)) return;      // uniform over the grid: every wave leaves before any barrier
@@ -360,9 +363,9 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
     const int b = blockIdx.x;
     const int q = T / 8, r = T % 8, xcd = b % 8;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-    const int per_group = 4 * gp.tiles_n;
-    const int grp = lid / per_group, first_m = grp * 4;
-    const int gsz = (gp.tiles_m - first_m) < 4 ? (gp.tiles_m - first_m) : 4;
+    const int per_group = PG_GENO_GRP * gp.tiles_n;
+    const int grp = lid / per_group, first_m = grp * PG_GENO_GRP;
+    const int gsz = (gp.tiles_m - first_m) < PG_GENO_GRP ? (gp.tiles_m - first_m) : PG_GENO_GRP;
     const int tm = first_m + (lid % per_group) % gsz, tn = (lid % per_group) / gsz;
     const long long m0 = (long long)tm * 256, n0 = (long long)tn * 256;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
