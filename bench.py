@@ -124,14 +124,14 @@ def spawn_ranks(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=10000)
     ap.add_argument("--c", type=int, default=5)
     ap.add_argument("--snps", type=int, default=100000, help="SNPs per GPU per step (configs[2]: p = 100,000)")
     ap.add_argument("--batch", type=int, default=16384, help="SNPs per HBM-resident batch")
     ap.add_argument("--grid", type=int, default=0, help="1 = calc_lambda_restricted(grid=True) path")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="SNPs of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="SNPs of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--null", type=int, default=0, help="1 = pure-noise phenotype (SURVEY 8d second phenotype) instead of the polygenic one")
     ap.add_argument("--weak", type=int, default=0, help="1 = weak-signal phenotype (h2 = 0.02): drives Newton towards its iteration cap")
     ap.add_argument("--fp32-rotate", type=int, default=0, help="1 = force the fp32-MFMA rotation even for genotype-valued X")
