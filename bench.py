@@ -42,12 +42,14 @@ def pmc_traffic(kernel):
     try:
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
-            v = json.load(open(f)).get("pmc", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+            j = json.load(open(f))
+            v = j.get("pmc", {}).get(kernel, {}).get("hbm_bytes_per_launch")
             if v is not None:
-                return v, os.path.relpath(f, ROOT)
+                sh = j.get("batch_shape", {"n": 10000, "batch": 16384, "c": 5})
+                return v, os.path.relpath(f, ROOT), (sh["n"], sh["batch"], sh["c"])
     except Exception:
         pass
-    return None, None
+    return None, None, None
 
 
 def host_cores():
@@ -129,7 +131,8 @@ def main():
     ap.add_argument("--n", type=int, default=10000)
     ap.add_argument("--c", type=int, default=5)
     ap.add_argument("--snps", type=int, default=100000, help="SNPs per GPU per step (configs[2]: p = 100,000)")
-    ap.add_argument("--batch", type=int, default=16384, help="SNPs per HBM-resident batch")
+    ap.add_argument("--batch", type=int, default=100000, help="SNPs per HBM-resident batch (the default holds the whole step in one: kernels long enough "
+                    "to settle at their own clocks; 16384 costs 3 %%)")
     ap.add_argument("--grid", type=int, default=0, help="1 = calc_lambda_restricted(grid=True) path")
     ap.add_argument("--cpu-sample", type=int, default=1024, help="SNPs of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--null", type=int, default=0, help="1 = pure-noise phenotype (SURVEY 8d second phenotype) instead of the polygenic one")
@@ -343,9 +346,9 @@ def main():
     # + per SNP-specific evaluation m(m+1)/2 entries x (2 | 3) powers x 2n
     assoc_flops_snp = 11 * 2 * m * 2.0 * n + (stats[0] * 2 + stats[1] * 3) * (m * (m + 1) / 2) * 2.0 * n
     used_geno = (not a.fp32_rotate) and used_path == 1
-    tr_rot, src_rot = pmc_traffic("rotate_geno_kernel" if used_geno else "rotate_kernel")
-    tr_as, src_as = pmc_traffic("assoc_kernel")
-    same_shape = (n, B, c) == (10000, 16384, 5)
+    tr_rot, src_rot, shape_rot = pmc_traffic("rotate_geno_kernel" if used_geno else "rotate_kernel")
+    tr_as, src_as, shape_as = pmc_traffic("assoc_kernel")
+    same_shape = (n, B, c) == shape_rot == shape_as          # the counters were collected per launch of this batch shape
     rl_rotate = ({"kernel": "rotate_geno_kernel (+detect/encode): fp16 MFMA 16x16x32, U split in 2 fp16 planes, fp32 accumulate",
                   "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12, "peak": F16_MFMA_PEAK_TF / 2.0, "unit": "TFLOP/s",
                   "frac": rot_flops / rot_avg / 1e12 / (F16_MFMA_PEAK_TF / 2.0),
