@@ -40,6 +40,9 @@ __all__ = ["pygemma", "SampleIter", "pinned_empty", "pin", "kinship"] + _model._
 
 _BATCH_BYTES = 6 << 30   # device bytes for one SNP batch of one worker (raw block, rotated block, fp16 planes)
 _BATCH_SNPS = 32768      # SNPs per batch at most: the unit of copy/compute overlap and of checkpointing
+_BATCH_MIN = 8192        # ... and at least, while the block is cut into up to _BATCH_COUNT batches: the first batch's DMA and the
+_BATCH_COUNT = 12        # last batch's kernels are the part of the loop that does not overlap (measured at p = 100 000: 4 batches
+                         # 0.149-0.172 s, 8: 0.116, 12: 0.112, 16: 0.112 — tools/ab_stream_batch.py)
 _STAGE_THREADS = 8       # host copy threads per worker for the pageable -> pinned leg
 
 
@@ -154,6 +157,8 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
             esz = 1 if x8 else (8 if x64 else 4)
             pb_max = max(256, int(_BATCH_BYTES // (12 * ldx)) // 256 * 256)   # raw block + rotated block + two fp16 planes
             pb_max = min(pb_max, _BATCH_SNPS, b - a)
+            nbat = max(-(-(b - a) // pb_max), min(_BATCH_COUNT, -(-(b - a) // _BATCH_MIN)))
+            pb_max = min(pb_max, (-(-(b - a) // nbat) + 255) // 256 * 256)
             ldX = (pb_max + 15) // 16 * 16
             bpr = (n + 3) // 4
             p = X.shape[1]
@@ -482,7 +487,7 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
         # identity of the run: shapes, options, batch geometry and the SNP-independent inputs themselves (rotated y, W and the
         # eigenvalues, byte for byte); the genotypes are fingerprinted per part (_block_fingerprint)
         key = {"n": int(n), "p": int(p), "c": int(c), "grid": bool(grid), "eigen": bool(eigen), "ndev": int(ndev), "lrt": bool(lrt),
-               "batch_snps": int(_BATCH_SNPS), "batch_bytes": int(_BATCH_BYTES),
+               "batch_snps": int(_BATCH_SNPS), "batch_bytes": int(_BATCH_BYTES), "batch_min": int(_BATCH_MIN), "batch_count": int(_BATCH_COUNT),
                "y_crc": _crc(yr1), "w_crc": _crc(Wr), "d_crc": _crc(eigenVals)}
         mf = os.path.join(checkpoint, "manifest.json")
         if os.path.exists(mf):
