@@ -20,6 +20,7 @@ result rows come back through a pinned buffer.  With several GPUs the eigenvecto
 RCCL broadcast over xGMI (pg_comm_*; no PyTorch).
 There is no CPU fallback: without the HIP library or a GPU this raises.
 """
+import contextlib
 import ctypes as C
 import json
 import os
@@ -40,6 +41,8 @@ __all__ = ["pygemma", "SampleIter", "pinned_empty", "pin", "kinship"] + _model._
 
 _BATCH_BYTES = 6 << 30   # device bytes for one SNP batch of one worker (raw block, rotated block, fp16 planes)
 _BATCH_SNPS = 32768      # SNPs per batch at most: the unit of copy/compute overlap and of checkpointing
+_WORKERS = 2             # host threads (each with its own stream and buffers) per GPU
+_SERIAL_KERNELS = False  # True: the workers of a GPU take turns on its compute units (measured: no gain for float32 X, 8 % slower for int8 X)
 _BATCH_MIN = 8192        # ... and at least, while the block is cut into up to _BATCH_COUNT batches: the first batch's DMA and the
 _BATCH_COUNT = 12        # last batch's kernels are the part of the loop that does not overlap (measured at p = 100 000: 4 batches
                          # 0.149-0.172 s, 8: 0.116, 12: 0.112, 16: 0.112 — tools/ab_stream_batch.py)
@@ -178,6 +181,7 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                 else:
                     todo.append((s, e))
             lock = threading.Lock()
+            gpu = threading.Lock() if _SERIAL_KERNELS else contextlib.nullcontext()   # one batch's kernels at a time; the other worker's DMA runs under them
             if stats is not None:
                 stats["setup_s"] = max(stats.get("setup_s", 0.0), time.time() - t_blk)
 
@@ -205,15 +209,14 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                 s, e = todo.pop(0)
                             pb = e - s
                             t_in = time.time()
-                            if packed:   # SNP records [s, e) of the .bed image: contiguous bytes; decode + impute + rotate on the device
+                            # ---- the raw block travels to the device on this worker's stream
+                            if packed:   # SNP records [s, e) of the .bed image: contiguous bytes
                                 rec = X.data[s:e]
                                 if rec.flags.c_contiguous:
                                     _lib.check(L.pg_stage_rows(stg.inp, rec.nbytes, rec.ctypes.data, rec.nbytes, rec.nbytes, 1, 1), "pg_stage_rows")
                                 else:
                                     C.memmove(stg.inp, np.ascontiguousarray(rec).ctypes.data, pb * bpr)
                                 _lib.check(L.pg_memcpy_h2d_async(ctx.handle, dX.ptr, stg.inp, pb * bpr), "pg_memcpy_h2d_async")
-                                _lib.check(L.pg_rotate_bed_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, bpr, int(X.count_A1), dXr.ptr, ldx,
-                                                               dwork.ptr), "pg_rotate_bed_dev")
                             else:
                                 src = X.ctypes.data + esz * s
                                 if direct:
@@ -222,7 +225,16 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                 else:    # pageable X: copy threads gather the column window into pinned staging, then one dense DMA
                                     _lib.check(L.pg_stage_rows(stg.inp, ldX * esz, src, p * esz, pb * esz, n, _STAGE_THREADS), "pg_stage_rows")
                                     _lib.check(L.pg_memcpy_h2d_async(ctx.handle, dX.ptr, stg.inp, n * ldX * esz), "pg_memcpy_h2d_async")
-                                if x64:
+                            if _SERIAL_KERNELS:
+                                ctx.sync()       # the block has landed; the kernels wait for the token, not for the link
+                            t_dma = time.time()
+                            with gpu:
+                                t_tok = time.time()
+                                # ---- rotation: decode + impute + rotate for .bed records; otherwise the path is chosen on the device
+                                if packed:
+                                    _lib.check(L.pg_rotate_bed_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, bpr, int(X.count_A1), dXr.ptr, ldx,
+                                                                   dwork.ptr), "pg_rotate_bed_dev")
+                                elif x64:
                                     is_geno = C.c_int(0)
                                     _lib.check(L.pg_rotate_geno_f64_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx, dwork.ptr,
                                                                         C.byref(is_geno)), "pg_rotate_geno_f64_dev")
@@ -238,18 +250,19 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                                                     dwork.ptr, None), "pg_rotate_auto_dev")
                                 else:
                                     _lib.check(L.pg_transpose_dev(ctx.handle, n, pb, dX.ptr, ldX, dXr.ptr, ldx), "pg_transpose_dev")
-                            # result block: [F | p | beta | se | tau | lambda] (+ [l_alt | l_null | D_lrt | p_lrt] f64 with lrt)
-                            r0 = dres.ptr
-                            if lrt:
-                                _lib.check(L.pg_assoc_lrt_dev(ctx.handle, n, c, pb, dd.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, int(grid),
-                                                              r0 + 16 * pb, r0 + 20 * pb, r0 + 24 * pb, r0 + 28 * pb, r0, r0 + 8 * pb,
-                                                              r0 + 32 * pb, r0 + 40 * pb, r0 + 48 * pb, r0 + 56 * pb), "pg_assoc_lrt_dev")
-                            else:
-                                _lib.check(L.pg_assoc_dev(ctx.handle, n, c, pb, dd.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, int(grid),
-                                                          r0 + 16 * pb, r0 + 20 * pb, r0 + 24 * pb, r0 + 28 * pb, r0, r0 + 8 * pb, None),
-                                           "pg_assoc_dev")
-                            _lib.check(L.pg_memcpy_d2h_async(ctx.handle, stg.out, r0, pb * nout), "pg_memcpy_d2h_async")
-                            ctx.sync()
+                                # result block: [F | p | beta | se | tau | lambda] (+ [l_alt | l_null | D_lrt | p_lrt] f64 with lrt)
+                                r0 = dres.ptr
+                                if lrt:
+                                    _lib.check(L.pg_assoc_lrt_dev(ctx.handle, n, c, pb, dd.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, int(grid),
+                                                                  r0 + 16 * pb, r0 + 20 * pb, r0 + 24 * pb, r0 + 28 * pb, r0, r0 + 8 * pb,
+                                                                  r0 + 32 * pb, r0 + 40 * pb, r0 + 48 * pb, r0 + 56 * pb), "pg_assoc_lrt_dev")
+                                else:
+                                    _lib.check(L.pg_assoc_dev(ctx.handle, n, c, pb, dd.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, int(grid),
+                                                              r0 + 16 * pb, r0 + 20 * pb, r0 + 24 * pb, r0 + 28 * pb, r0, r0 + 8 * pb, None),
+                                               "pg_assoc_dev")
+                                _lib.check(L.pg_memcpy_d2h_async(ctx.handle, stg.out, r0, pb * nout), "pg_memcpy_d2h_async")
+                                ctx.sync()
+                                t_ker = time.time()
                             hb = np.frombuffer(hres, np.uint8, pb * nout)
                             FP = hb[:16 * pb].view(np.float64).reshape(2, pb)
                             res = hb[16 * pb:32 * pb].view(np.float32).reshape(4, pb)
@@ -265,6 +278,9 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                     stats["batches"] += 1
                                     stats["bytes_in"] += pb * bpr if packed else n * pb * esz
                                     stats["batch_s"] += time.time() - t_in
+                                    stats["dma_s"] = stats.get("dma_s", 0.0) + (t_dma - t_in)       # copy-in (waited for only when the kernels are serialised)
+                                    stats["token_s"] = stats.get("token_s", 0.0) + (t_tok - t_dma)  # waiting for the other worker's kernels
+                                    stats["kernel_s"] = stats.get("kernel_s", 0.0) + (t_ker - t_tok)
                             if ckpt:
                                 tmp = _part_path(ckpt, s, e) + ".tmp.npz"
                                 np.savez(tmp, fingerprint=np.int64(_block_fingerprint(X, s, e)),
@@ -279,7 +295,7 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                 except Exception as ex:  # surfaced by the caller; never swallowed
                     errs.append(ex)
 
-            workers = [threading.Thread(target=worker) for _ in range(min(2, len(todo)))]
+            workers = [threading.Thread(target=worker) for _ in range(min(_WORKERS, len(todo)))]
             for th in workers:
                 th.start()
             for th in workers:
@@ -527,6 +543,8 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
             threads.append(th)
         for th in threads:
             th.join()
+        if stats is not None:
+            stats["blocks_s"] = time.time() - t2          # page-locking + every GPU's block; what follows is teardown (frees)
     finally:
         if xpin is not None:
             xpin.close()

@@ -15,8 +15,10 @@ ref = None
 for tag, Xin in (("f32 pinned", Xp), ("int8 pageable", X8)):
     for bs in sizes + sizes[:1]:
         lmm._BATCH_SNPS = bs
+        lmm._WORKERS = int(os.environ.get('PG_AB_WORKERS', lmm._WORKERS)); lmm._BATCH_COUNT = int(os.environ.get('PG_AB_COUNT', lmm._BATCH_COUNT)); lmm._SERIAL_KERNELS = bool(int(os.environ.get('PG_AB_SERIAL', '1')))
         st = {}
         t = time.time(); df = lmm.pygemma(y, Xin, W, K, stats=st); dt = time.time() - t
         if ref is None: ref = df
         same = bool((df["beta"].to_numpy() == ref["beta"].to_numpy()).all())
+        print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()})
         print(f"{tag:14s} batch {bs:6d}: wall {dt:.3f} s; loop {st.get('seconds', float('nan')):.4f} s; batches {st.get('batches')}; same beta as first run: {same}", flush=True)
