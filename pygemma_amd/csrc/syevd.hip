@@ -688,6 +688,19 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
         t_prev = t;
     };
     std::vector<double> d(d_in, d_in + n), e(e_in, e_in + (n > 1 ? n - 1 : 0));
+    // The deflation tolerances of the merges compare eigenvalue-scale quantities with components of unit vectors (as dlaed2 does):
+    // like dstedc, work on T scaled to max-norm ~ 1 — by a power of two, so that the scaling itself rounds nothing.
+    double orgnrm = 0.0;
+    for (double v : d) orgnrm = std::max(orgnrm, fabs(v));
+    for (double v : e) orgnrm = std::max(orgnrm, fabs(v));
+    double unscale = 1.0;
+    if (orgnrm > 0.0 && std::isfinite(orgnrm)) {
+        const int ex = std::ilogb(orgnrm);
+        const double sc = std::ldexp(1.0, -ex);
+        unscale = std::ldexp(1.0, ex);
+        for (double &v : d) v *= sc;
+        for (double &v : e) v *= sc;
+    }
     // ---- leaves
     const int nleaf = (n + DC_LEAF - 1) / DC_LEAF;
     std::vector<int> bs(nleaf + 1);
@@ -812,7 +825,7 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
     std::iota(idx.begin(), idx.end(), 0);
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return d[a] < d[b]; });
     evals.resize(n);
-    for (int i = 0; i < n; i++) evals[i] = d[idx[i]];
+    for (int i = 0; i < n; i++) evals[i] = d[idx[i]] * unscale;
     PG_HIP(hipMemcpyAsync(wk.ibuf, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
     permute_final_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n, Qin, wk.ibuf, Qout);
     PG_HIP(hipGetLastError());
@@ -1037,9 +1050,14 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
         }
         if (!rc && n != n0) {
             if (he[n - 2] != 0.0) { set_error("pg_syevd_dev: padding row did not stay decoupled (e = %g)", he[n - 2]); rc = PG_EHIP; }
-            double top = 0.0;   // Gershgorin bound of the leading n0 x n0 tridiagonal
-            for (int i = 0; i < n0; i++) top = std::max(top, hd[i] + (i > 0 ? fabs(he[i - 1]) : 0.0) + (i + 1 < n0 ? fabs(he[i]) : 0.0));
-            hd[n - 1] = top + std::max(1.0, fabs(top));
+            double top = 0.0, nrm = 0.0;   // Gershgorin bound and max-norm of the leading n0 x n0 tridiagonal
+            for (int i = 0; i < n0; i++) {
+                top = std::max(top, hd[i] + (i > 0 ? fabs(he[i - 1]) : 0.0) + (i + 1 < n0 ? fabs(he[i]) : 0.0));
+                nrm = std::max(nrm, std::max(fabs(hd[i]), i + 1 < n0 ? fabs(he[i]) : 0.0));
+            }
+            // strictly above every eigenvalue, and of the matrix's own magnitude: a constant here (it was max(1, |top|)) would set the
+            // scale of T for the divide & conquer and drown a K of norm << 1 in its deflation tolerances
+            hd[n - 1] = top + (nrm > 0.0 ? nrm : 1.0);
         }
     }
     mark("tridiagonalise");

@@ -126,3 +126,57 @@ def test_syevd_invariants(n, ctx):
     assert res <= 1e-12 * np.sqrt(n)
     assert (ev32 == np.maximum(ev, 0).astype(np.float32)).all() and (ev32 >= 0).all()
     assert (U32 == U.astype(np.float32)).all()
+
+
+def _structured(name, n, rng):
+    """Relatedness matrices with the degeneracies real cohorts have (the path's K is whatever the caller computed, lmm.py:151)."""
+    if name == "rank_deficient":            # fewer SNPs than samples: n - p exact zero eigenvalues
+        G = rng.binomial(2, 0.3, size=(n, n // 4)).astype(np.float64); G -= G.mean(0)
+        return G @ G.T / G.shape[1]
+    if name == "block_diagonal":            # unrelated families: the tridiagonal form splits
+        K = np.zeros((n, n)); s = 0
+        while s < n:
+            b = min(int(rng.integers(1, 40)), n - s)
+            A = rng.standard_normal((b, 3 * b)); K[s:s + b, s:s + b] = A @ A.T / (3 * b); s += b
+        return K
+    if name == "identity_plus_tiny":
+        A = rng.standard_normal((n, n)) * 1e-9
+        return np.eye(n) + (A + A.T)
+    if name == "rank_one":
+        return np.ones((n, n))
+    if name == "zero":
+        return np.zeros((n, n))
+    if name == "duplicated_samples":        # monozygotic twins / sample duplicates: exactly repeated rows and columns
+        G = rng.binomial(2, 0.3, size=(n, 2 * n)).astype(np.float64)
+        G[n // 2:] = G[: n - n // 2]
+        G -= G.mean(0)
+        return G @ G.T / G.shape[1]
+    if name == "diagonal":
+        return np.diag(rng.uniform(0.5, 2.0, n))
+    if name == "huge_scale":
+        A = rng.standard_normal((n, n)); return (A @ A.T) * 1e30
+    if name == "tiny_scale":
+        A = rng.standard_normal((n, n)); return (A @ A.T) * 1e-30
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["rank_deficient", "block_diagonal", "identity_plus_tiny", "rank_one", "zero", "duplicated_samples",
+                                  "diagonal", "huge_scale", "tiny_scale"])
+@pytest.mark.parametrize("n", [130, 601])
+def test_syevd_structured_matrices(name, n, ctx):
+    """Degenerate spectra through the whole solver (Householder with zero columns, deflation-heavy merges, splits): same Tier-B
+    invariants on the float64 outputs; the scales 1e+-30 sit near the ends of the float32 range K arrives in."""
+    from pygemma_amd import ops
+    rng = np.random.default_rng(7 * n + len(name))
+    K = _structured(name, n, rng).astype(np.float32)
+    K64 = np.tril(K.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
+    ev32, U32, ev, U = ops.syevd(K, ctx=ctx, want64=True)
+    assert np.isfinite(ev).all() and np.isfinite(U).all()
+    ref = np.linalg.eigvalsh(K64)
+    lmax = max(np.abs(ref).max(), 1e-300)
+    assert np.all(np.diff(ev) >= 0)
+    assert np.abs(ev - ref).max() <= 1e-12 * lmax
+    assert np.abs(U.T @ U - np.eye(n)).max() <= 1e-12
+    res = np.linalg.norm(K64 - (U * ev) @ U.T) / max(np.linalg.norm(K64), 1e-300)
+    assert res <= 1e-12 * np.sqrt(n)
+    assert (ev32 >= 0).all() and np.isfinite(U32).all()
