@@ -99,6 +99,8 @@ __device__ __forceinline__ float np_logf(float x)
     const float q1 = 2.612677543073109236779e+00f, q2 = 2.453006071784736363091e+00f,
                 q3 = 9.864942958519418960339e-01f, q4 = 1.546476374983906719538e-01f,
                 q5 = 5.875095403124574342950e-03f;
+    // anything but a positive finite argument (an eigenvalue handed over as inf / NaN / negative): numpy's special values
+    if (__builtin_expect(!(x > 0.0f) || x == INFINITY, 0)) return (x != x) ? x : (x < 0.0f ? NAN : (x == 0.0f ? -INFINITY : x));
     unsigned u = __float_as_uint(x);
     int e = (int)((u >> 23) & 0xff) - 126;
     float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
