@@ -62,3 +62,51 @@ def fast_rotated_panel(n, p, c, seed=SEED, null=False):
         y = (rng.standard_normal(n) * np.sqrt(0.5 * (lam * d.astype(np.float64) + 1.0))).astype(np.float32)
         y += 0.05 * X[:, 0]
     return {"d": d, "X": X, "Y": y.reshape(-1, 1), "W": W}
+
+
+def degenerate_panels(seed=0, n=203, c=3, p=16):
+    """(tag, d, W, y, X) with the degeneracies a caller can hand over at the eigen-basis boundary (eigen=False passes eigenvalues
+    through unclamped, lmm/lmm.py:196-207 clamps only what it computes itself): SNP columns that are zero / constant / collinear
+    with W or y / scaled to the ends of the float32 range / holding NaN or inf, eigenvalues that are zero, huge, tiny, inf, NaN or
+    negative, phenotypes and covariates that are zero, scaled, duplicated or non-finite."""
+    rng = np.random.default_rng(seed)
+    d = np.sort(rng.gamma(0.5, 2.0, n)).astype(np.float32)
+    W = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, c - 1))], axis=1).astype(np.float32)
+    X = rng.binomial(2, 0.3, size=(n, p)).astype(np.float32) - np.float32(0.6)
+    y = (W @ rng.standard_normal(c) + 0.5 * X[:, 0] + rng.standard_normal(n)).astype(np.float32)
+    X[:, 0] = 0.0; X[:, 1] = 3.0; X[:, 2] = W[:, 0]; X[:, 3] = W[:, -1]; X[:, 4] = y
+    X[:, 5] *= np.float32(1e30); X[:, 6] *= np.float32(1e-30); X[:, 7] *= np.float32(1e-42)
+    X[3, 8] = np.nan; X[5, 9] = np.inf; X[5, 10] = -np.inf
+    X[:, 11] = 2.0 * W[:, 1] - W[:, 0]
+    X[:, 12] = (np.arange(n) == 0)
+    with np.errstate(over="ignore"):
+        X[:, 13] *= np.float32(3e38)        # overflows to +-inf where |x| > 1
+    i = np.arange(n)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    yield "plain", d, W, y, X
+    yield "d = 0", np.zeros_like(d), W, y, X
+    yield "d huge", f32(d * np.float32(1e10)), W, y, X
+    yield "d half zero", f32(np.where(i < n // 2, 0, d)), W, y, X
+    yield "d tiny", f32(d * np.float32(1e-30)), W, y, X
+    yield "d with inf", f32(np.where(i == n - 1, np.inf, d)), W, y, X
+    yield "d with NaN", f32(np.where(i == 4, np.nan, d)), W, y, X
+    yield "d one negative", f32(np.where(i == 0, -0.5, d)), W, y, X
+    yield "d negative small", f32(np.where(i < 3, -1e-4, d)), W, y, X
+    yield "y = 0", d, W, np.zeros_like(y), X
+    yield "y * 1e20", d, W, f32(y * np.float32(1e20)), X
+    yield "y * 1e-20", d, W, f32(y * np.float32(1e-20)), X
+    yield "y = w0", d, W, W[:, 0].copy(), X
+    yield "y with NaN", d, W, f32(np.where(i == 7, np.nan, y)), X
+    yield "W duplicate column", d, f32(np.concatenate([W[:, :2], W[:, 1:2]], axis=1)), y, X
+    yield "W zero column", d, f32(np.concatenate([W[:, :2], np.zeros((n, 1))], axis=1)), y, X
+    yield "W * 1e20", d, f32(W * np.float32(1e20)), y, X
+    yield "W with NaN", d, f32(np.where((i == 9)[:, None] & (np.arange(c) == 1)[None, :], np.nan, W)), y, X
+
+
+# Rows of degenerate_panels() on which the outcome is cancellation noise (beta ~ 1e29, tau = 1.99e37 ...) and follows the summation
+# order inside the reference's BLAS calls, which no restatement reproduces; keyed by the oracle's order (0: the reference's own,
+# 1: the kernels').  The NaN pattern is compared on every row; values only off these.
+DEGENERATE_SINGULAR_SNPS = {0: (1, 11),          # x constant (collinear with the intercept), x in span(W)
+                            1: (1, 2, 3, 4, 11)}  # ... and x = w0, x = w_last, x = y (perfect fit: the residual is rounding noise)
+DEGENERATE_SINGULAR_CASES = {0: ("W duplicate column",),
+                             1: ("W duplicate column", "y = w0", "y = 0")}   # y in span(W): every statistic is residual noise

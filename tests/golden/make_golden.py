@@ -348,3 +348,32 @@ def gen_lrt():
 
 if __name__ == "__main__" and "lrt" in sys.argv[1:]:
     gen_lrt()
+
+
+def gen_degenerate():
+    """The degenerate panels of synth.degenerate_panels() (zero / collinear / non-finite SNPs, eigenvalues that are zero, inf, NaN
+    or negative, degenerate y and W) through the real reference's live path, lmm.pygemma(..., eigen=False), for both lambda
+    paths.  A case on which the reference raises is stored as such (its message), not skipped."""
+    out = {"versions": VERS}
+    tags = []
+    for k, (tag, d, W, y, X) in enumerate(synth.degenerate_panels()):
+        tags.append(tag)
+        for nm, v in (("d", d), ("W", W), ("y", y), ("X", X)):
+            out[f"c{k}_{nm}"] = v
+        for grid in (False, True):
+            key = f"c{k}_{'grid' if grid else 'brent'}"
+            try:
+                df = quiet(ref.pygemma, y.reshape(-1, 1), X, W, d, grid=grid, eigen=False, nproc=1)
+                for col in ["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"]:
+                    out[f"{key}_{col}"] = df[col].to_numpy()
+                out[f"{key}_raised"] = np.array("")
+                print(f"{tag:22s} grid={grid}: {int(np.isnan(df['beta'].to_numpy()).sum())} NaN rows of {len(df)}")
+            except Exception as ex:
+                out[f"{key}_raised"] = np.array(f"{type(ex).__name__}: {ex}"[:300])
+                print(f"{tag:22s} grid={grid}: RAISED {type(ex).__name__}: {str(ex)[:120]}")
+    out["tags"] = np.array(tags)
+    np.savez_compressed(os.path.join(HERE, "degenerate_panels.npz"), **out)
+
+
+if __name__ == "__main__" and "degenerate" in sys.argv[1:]:
+    gen_degenerate()

@@ -92,52 +92,13 @@ def test_reference_test_matrices_collinear_snp_c12(ctx):
     assert abs(got["tau"][0] - z["df_tau"][0]) <= 1e-4 * abs(z["df_tau"][0])
 
 
-def _degenerate_panels(seed=0, n=203, c=3, p=16):
-    """(tag, d, W, y, X) with the degeneracies a caller can hand over at the eigen-basis boundary (eigen=False passes eigenvalues
-    through unclamped, lmm/lmm.py:196-207 clamps only what it computes itself): SNP columns that are zero / constant / collinear
-    with W or y / scaled to the ends of the float32 range / holding NaN or inf, eigenvalues that are zero, huge, tiny, inf, NaN or
-    negative, phenotypes and covariates that are zero, scaled, duplicated or non-finite."""
-    rng = np.random.default_rng(seed)
-    d = np.sort(rng.gamma(0.5, 2.0, n)).astype(np.float32)
-    W = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, c - 1))], axis=1).astype(np.float32)
-    X = rng.binomial(2, 0.3, size=(n, p)).astype(np.float32) - np.float32(0.6)
-    y = (W @ rng.standard_normal(c) + 0.5 * X[:, 0] + rng.standard_normal(n)).astype(np.float32)
-    X[:, 0] = 0.0; X[:, 1] = 3.0; X[:, 2] = W[:, 0]; X[:, 3] = W[:, -1]; X[:, 4] = y
-    X[:, 5] *= np.float32(1e30); X[:, 6] *= np.float32(1e-30); X[:, 7] *= np.float32(1e-42)
-    X[3, 8] = np.nan; X[5, 9] = np.inf; X[5, 10] = -np.inf
-    X[:, 11] = 2.0 * W[:, 1] - W[:, 0]
-    X[:, 12] = (np.arange(n) == 0)
-    with np.errstate(over="ignore"):
-        X[:, 13] *= np.float32(3e38)        # overflows to +-inf where |x| > 1
-    i = np.arange(n)
-    f32 = lambda a: np.ascontiguousarray(a, np.float32)
-    yield "plain", d, W, y, X
-    yield "d = 0", np.zeros_like(d), W, y, X
-    yield "d huge", f32(d * np.float32(1e10)), W, y, X
-    yield "d half zero", f32(np.where(i < n // 2, 0, d)), W, y, X
-    yield "d tiny", f32(d * np.float32(1e-30)), W, y, X
-    yield "d with inf", f32(np.where(i == n - 1, np.inf, d)), W, y, X
-    yield "d with NaN", f32(np.where(i == 4, np.nan, d)), W, y, X
-    yield "d one negative", f32(np.where(i == 0, -0.5, d)), W, y, X
-    yield "d negative small", f32(np.where(i < 3, -1e-4, d)), W, y, X
-    yield "y = 0", d, W, np.zeros_like(y), X
-    yield "y * 1e20", d, W, f32(y * np.float32(1e20)), X
-    yield "y * 1e-20", d, W, f32(y * np.float32(1e-20)), X
-    yield "y = w0", d, W, W[:, 0].copy(), X
-    yield "y with NaN", d, W, f32(np.where(i == 7, np.nan, y)), X
-    yield "W duplicate column", d, f32(np.concatenate([W[:, :2], W[:, 1:2]], axis=1)), y, X
-    yield "W zero column", d, f32(np.concatenate([W[:, :2], np.zeros((n, 1))], axis=1)), y, X
-    yield "W * 1e20", d, f32(W * np.float32(1e20)), y, X
-    yield "W with NaN", d, f32(np.where((i == 9)[:, None] & (np.arange(c) == 1)[None, :], np.nan, W)), y, X
-
-
 @pytest.mark.parametrize("grid", [False, True])
 def test_degenerate_inputs_same_bits_and_same_nans_as_oracle(grid, ctx):
     """Nothing raises, hangs or differs on degenerate inputs: every column equals the oracle (kernel order) bit for bit, NaN where
     the oracle has NaN (tools/adversarial_assoc.py is the same sweep with a report per case)."""
     from oracle import oracle as O
-    from pygemma_amd import ops
-    for tag, d, W, y, X in _degenerate_panels():
+    from pygemma_amd import ops, synth
+    for tag, d, W, y, X in synth.degenerate_panels():
         got = ops.assoc(d, W, y, X, grid=grid, ctx=ctx)
         orc = O.calculate(d, y, W, X, grid=grid, order=1, nthreads=4)
         for col in ("beta", "se_beta", "tau", "lambda", "F_wald"):
@@ -147,3 +108,28 @@ def test_degenerate_inputs_same_bits_and_same_nans_as_oracle(grid, ctx):
             assert same.all(), (tag, col, np.nonzero(~same)[0][:5], a[~same][:3], b[~same][:3])
         a, b = got["p_wald"], orc["p_wald"]
         assert (np.isclose(a, b, rtol=1e-8, atol=0) | (np.isnan(a) & np.isnan(b))).all(), (tag, "p_wald")
+
+
+@pytest.mark.parametrize("grid", [False, True])
+def test_degenerate_panels_through_lmm_vs_reference_fixture(grid):
+    """The same panels through lmm.pygemma(eigen=False) against what the REAL reference returned for them
+    (tests/golden/degenerate_panels.npz): negative eigenvalues clamped like lmm/lmm.py:166-167, the same rows NaN, no exception,
+    and on the well-posed rows the reference's numbers (float32 last-bit tolerance of the kernels' summation order)."""
+    import os
+    from pygemma import lmm
+    from pygemma_amd.synth import DEGENERATE_SINGULAR_CASES as _SINGULAR_CASES, DEGENERATE_SINGULAR_SNPS as _SINGULAR_SNPS
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "degenerate_panels.npz"))
+    for k, tag in enumerate(z["tags"]):
+        d, W, y, X = (z[f"c{k}_{nm}"] for nm in "dWyX")
+        key = f"c{k}_{'grid' if grid else 'brent'}"
+        df = lmm.pygemma(y.reshape(-1, 1), X, W, d, eigen=False, grid=grid)
+        keep = np.ones(X.shape[1], bool)
+        keep[list(_SINGULAR_SNPS[1])] = False
+        if tag in _SINGULAR_CASES[1]:
+            keep[:] = False
+        for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
+            r, a = z[f"{key}_{col}"].astype(np.float64), df[col].to_numpy().astype(np.float64)
+            assert (np.isnan(a) == np.isnan(r)).all(), (tag, col)
+            a, r = a[keep], r[keep]
+            same = np.isclose(a, r, rtol=2e-4, atol=0) | (np.isnan(a) & np.isnan(r)) | (a == r)
+            assert same.all(), (tag, col, np.nonzero(~same)[0], a[~same][:3], r[~same][:3])

@@ -255,3 +255,38 @@ def test_ml_scalar_functions_vs_reference_fixtures():
                     assert abs(o[0] / fn[si, li, 0] - 1) <= 2e-6, (name, si, lam)
                 if 1e-3 < lam < 1e4:
                     assert abs(o[1] / fn[si, li, 1] - 1) <= 1e-3 and abs(o[2] / fn[si, li, 2] - 1) <= 2e-3, (name, si, lam, o, fn[si, li])
+
+
+from pygemma_amd.synth import DEGENERATE_SINGULAR_CASES as _SINGULAR_CASES, DEGENERATE_SINGULAR_SNPS as _SINGULAR_SNPS  # noqa: E402
+
+
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("grid", [False, True])
+def test_degenerate_panels_vs_reference(grid, order):
+    """synth.degenerate_panels() through the real reference's lmm.pygemma(eigen=False) (fixture made by make_golden.py degenerate;
+    the reference never raises on them: it returns rows): same NaN rows and, in the reference's own summation order, the same bits,
+    with eigenvalues clamped at 0 as lmm/lmm.py:166-167 does before the scan."""
+    z = np.load(os.path.join(G, "degenerate_panels.npz"))
+    compared = 0
+    for k, tag in enumerate(z["tags"]):
+        d, W, y, X = (z[f"c{k}_{nm}"] for nm in "dWyX")
+        key = f"c{k}_{'grid' if grid else 'brent'}"
+        assert str(z[f"{key}_raised"]) == ""
+        o = O.calculate(np.maximum(np.float32(0.0), d), y, W, X, grid=grid, order=order, nthreads=4)
+        keep = np.ones(X.shape[1], bool)
+        if not grid or order == 1:      # order 0 on the grid path agrees even on the singular designs
+            keep[list(_SINGULAR_SNPS[order])] = False
+            if tag in _SINGULAR_CASES[order]:
+                keep[:] = False
+        for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
+            r = z[f"{key}_{col}"]
+            a = np.asarray(o[col]).astype(r.dtype)
+            assert (np.isnan(a) == np.isnan(r)).all(), (tag, col)           # the same rows are NaN, singular designs included
+            a, r = a[keep], r[keep]
+            if order == 0 and col != "p_wald":
+                same = (a == r) | (np.isnan(a) & np.isnan(r))
+            else:       # kernel order: float32 last-bit differences allowed, as on the regular panels; p through another betainc
+                same = np.isclose(a, r, rtol=1e-8 if order == 0 else 2e-4, atol=0) | (np.isnan(a) & np.isnan(r)) | (a == r)
+            assert same.all(), (tag, col, np.nonzero(~same)[0], a[~same][:3], r[~same][:3])
+            compared += int(keep.sum())
+    assert compared >= 15 * 11 * 6
