@@ -241,3 +241,45 @@ def test_pygemma_float64_K_rounded_on_device():
     b = lmm.pygemma(y, X, W, K64.astype(np.float32))
     for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
         assert (a[col].to_numpy() == b[col].to_numpy()).all(), col
+
+
+@pytest.mark.parametrize("kind", ["rank_deficient", "duplicated_samples", "block_diagonal", "scaled_1e-6", "zero"])
+def test_pygemma_full_pipeline_degenerate_relatedness_matrices(kind):
+    """Tier C on relatedness matrices with degenerate spectra (odd n: the padded eigensolver path): eigenspaces of repeated
+    eigenvalues have no unique basis, the statistics do not depend on it — they must agree with an fp64 pipeline (numpy eigh +
+    fp64 rotation + the oracle in the reference's order) far inside one standard error (tools/robust_K.py: the same with a report)."""
+    from oracle import oracle as O
+    from pygemma import lmm
+    rng = np.random.default_rng(5)
+    n, p, c = 401, 48, 3
+    G = rng.binomial(2, 0.3, size=(n, 4 * n)).astype(np.float64)
+    G = (G - G.mean(0)) / np.maximum(G.std(0), 1e-9)
+    if kind == "rank_deficient":
+        K = G[:, : n // 4] @ G[:, : n // 4].T / (n // 4)
+    elif kind == "duplicated_samples":
+        G[n // 2:] = G[: n - n // 2]
+        K = G @ G.T / G.shape[1]
+    elif kind == "block_diagonal":
+        K = np.zeros((n, n)); s = 0
+        while s < n:
+            b = min(int(rng.integers(2, 30)), n - s)
+            A = rng.standard_normal((b, 3 * b)); K[s:s + b, s:s + b] = A @ A.T / (3 * b); s += b
+    elif kind == "scaled_1e-6":
+        K = G @ G.T / G.shape[1] * 1e-6
+    else:
+        K = np.zeros((n, n))
+    K32 = K.astype(np.float32)
+    K64 = np.tril(K32.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
+    d, U = np.linalg.eigh(K64)
+    X = rng.binomial(2, 0.25, size=(n, p)).astype(np.float32)
+    W = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, c - 1))], axis=1).astype(np.float32)
+    g = U @ (np.sqrt(np.maximum(d, 0) / max(np.abs(d).max(), 1e-300)) * rng.standard_normal(n))
+    y = (0.4 * X[:, 0] + 0.7 * g + 0.7 * rng.standard_normal(n)).astype(np.float32).reshape(-1, 1)
+    rot = lambda A: (U.T @ A.astype(np.float64)).astype(np.float32)
+    for grid in (False, True):
+        df = lmm.pygemma(y, X, W, K32, grid=grid)
+        tr = O.calculate(np.maximum(d, 0).astype(np.float32), rot(y), rot(W), rot(X), grid=grid, order=0, nthreads=4)
+        b, t, se = df["beta"].to_numpy().astype(np.float64), tr["beta"].astype(np.float64), tr["se_beta"].astype(np.float64)
+        assert np.isfinite(b).all() and np.isfinite(t).all()
+        assert (np.abs(b - t) / se).max() < 1e-3, (kind, grid, (np.abs(b - t) / se).max())
+        np.testing.assert_allclose(df["p_wald"].to_numpy(), tr["p_wald"], rtol=2e-3)
