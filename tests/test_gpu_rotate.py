@@ -137,3 +137,35 @@ def test_rotate_auto_device_side_path_choice_equals_host_side(ctx):
             assert same.all() and np.isnan(got[9, :n]).all() and np.isfinite(got[8, :n]).all()
         else:
             assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+def test_rotate_auto_extreme_magnitudes(ctx):
+    """pg_rotate_auto_dev on blocks at the ends of the float32 range (genotype codes with steps 1e-40 ... 1e20 and a 1e6 offset,
+    dosages and normal values scaled per column / per element over 40-70 decades, denormals, values near FLT_MAX, a block holding
+    one inf or NaN): float32's own error bound 4 * 2^-24 sqrt(n) sum|x||u| against an fp64 rotation, every finite column finite,
+    the non-finite pattern of the exact product kept (tools/adversarial_rotate.py prints the same per case)."""
+    from pygemma_amd import ops
+    rng = np.random.default_rng(3)
+    n, p = 777, 40
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    U = Q.astype(np.float32)
+    geno = rng.binomial(2, 0.3, size=(n, p)).astype(np.float64)
+    norm = rng.standard_normal((n, p))
+    at = (np.arange(n)[:, None] == 5) & (np.arange(p)[None, :] == 7)
+    blocks = [(geno * 1e20, 1), (geno * 1e-20, 1), (geno * 1e-40, 1), (geno - 1e6, 1), (geno * (10.0 ** rng.integers(-30, 30, p))[None, :], 1),
+              (geno + rng.uniform(-0.3, 0.3, geno.shape), 2), (norm * 1e30, 2), (norm * 1e-30, 2), (norm * 1e-40, 2),
+              (norm * (10.0 ** rng.integers(-35, 35, p))[None, :], 2), (norm * (10.0 ** rng.integers(-20, 20, norm.shape)), 2),
+              (norm * 3e38 / np.abs(norm).max(), 2), (np.zeros((n, p)), 1), (np.where(at, np.inf, norm), 0), (np.where(at, np.nan, geno), 0)]
+    for Xd, want_path in blocks:
+        X = Xd.astype(np.float32)
+        got, path = ops.rotate_auto(U, X, ctx=ctx)
+        assert path == want_path
+        got, X64 = got[:, :n].astype(np.float64), X.astype(np.float64)
+        with np.errstate(invalid="ignore", over="ignore"):
+            exact = (U.astype(np.float64).T @ X64).T
+            bound = np.abs(X64).T @ np.abs(U.astype(np.float64))
+        fin = np.isfinite(X64).all(0)
+        assert np.isfinite(got[fin]).all()
+        err = np.abs(got[fin] - exact[fin])
+        assert ((err <= 4 * 2.0 ** -24 * np.sqrt(n) * bound[fin]) | (err <= 1.5e-45 * n)).all()
+        assert not np.isfinite(got[~fin]).any() or fin.all()       # a column holding inf / NaN comes out non-finite
