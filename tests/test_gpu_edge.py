@@ -133,3 +133,65 @@ def test_degenerate_panels_through_lmm_vs_reference_fixture(grid):
             a, r = a[keep], r[keep]
             same = np.isclose(a, r, rtol=2e-4, atol=0) | (np.isnan(a) & np.isnan(r)) | (a == r)
             assert same.all(), (tag, col, np.nonzero(~same)[0], a[~same][:3], r[~same][:3])
+
+
+def test_every_entry_point_rejects_bad_arguments_before_any_launch(ctx):
+    """The C ABI never throws or faults on misuse ('Error behaviour'): NULL pointers, empty or negative shapes,
+    leading dimensions smaller than the rows they describe and unsupported covariate counts come back as a negative code with a
+    message — checked on the host, before any kernel could read out of bounds — and the context keeps working afterwards."""
+    import ctypes as C
+    from pygemma_amd import _lib, ops, synth
+    L = _lib.load()
+    n, p, c = 64, 8, 2
+    buf = ctx.alloc(1 << 20)                      # one valid device buffer stands in for every non-NULL pointer argument
+    b, h = buf.ptr, ctx.handle
+    host = np.zeros(4096, np.float64)
+    hp = host.ctypes.data
+    ok_ld = 64
+    bad = [
+        ("pg_syevd_dev n=0", lambda: L.pg_syevd_dev(h, 0, b, b, b, None, None)),
+        ("pg_syevd_dev NULL K", lambda: L.pg_syevd_dev(h, n, None, b, b, None, None)),
+        ("pg_syevd_dev no outputs", lambda: L.pg_syevd_dev(h, n, b, None, b, None, None)),
+        ("pg_syevd_dev n too large", lambda: L.pg_syevd_dev(h, 70000, b, b, b, None, None)),
+        ("pg_rotate_dev ldX < p", lambda: L.pg_rotate_dev(h, n, p, b, n, b, p - 1, b, ok_ld)),
+        ("pg_rotate_dev ldU < n", lambda: L.pg_rotate_dev(h, n, p, b, n - 1, b, p, b, ok_ld)),
+        ("pg_rotate_dev ldx < n", lambda: L.pg_rotate_dev(h, n, p, b, n, b, p, b, n - 1)),
+        ("pg_rotate_dev p = 0", lambda: L.pg_rotate_dev(h, n, 0, b, n, b, p, b, ok_ld)),
+        ("pg_rotate_dev NULL U", lambda: L.pg_rotate_dev(h, n, p, None, n, b, p, b, ok_ld)),
+        ("pg_rotate_dev NULL ctx", lambda: L.pg_rotate_dev(None, n, p, b, n, b, p, b, ok_ld)),
+        ("pg_geno_prep_dev n=0", lambda: L.pg_geno_prep_dev(h, 0, b, n, b)),
+        ("pg_geno_prep_dev ldU < n", lambda: L.pg_geno_prep_dev(h, n, b, n - 1, b)),
+        ("pg_rotate_auto_dev ldX < p", lambda: L.pg_rotate_auto_dev(h, n, p, b, n, b, b, p - 1, b, ok_ld, b, None)),
+        ("pg_rotate_auto_dev NULL work", lambda: L.pg_rotate_auto_dev(h, n, p, b, n, b, b, p, b, ok_ld, None, None)),
+        ("pg_rotate_auto_i8_dev n<0", lambda: L.pg_rotate_auto_i8_dev(h, -1, p, b, b, 0, p, b, ok_ld, b, None)),
+        ("pg_rotate_bed_dev ldb too small", lambda: L.pg_rotate_bed_dev(h, n, p, b, b, n // 4 - 1, 0, b, ok_ld, b)),
+        ("pg_transpose_dev ldx < n", lambda: L.pg_transpose_dev(h, n, p, b, p, b, n - 1)),
+        ("pg_kinship_geno_dev p=0", lambda: L.pg_kinship_geno_dev(h, n, 0, b, p, 1, b)),
+        ("pg_kinship_geno_dev ldG < p", lambda: L.pg_kinship_geno_dev(h, n, p, b, p - 1, 1, b)),
+        ("pg_assoc_dev n=1", lambda: L.pg_assoc_dev(h, 1, c, p, b, b, b, b, ok_ld, 0, b, b, b, b, b, b, None)),
+        ("pg_assoc_dev ldx < n", lambda: L.pg_assoc_dev(h, n, c, p, b, b, b, b, n - 1, 0, b, b, b, b, b, b, None)),
+        ("pg_assoc_dev p < 0", lambda: L.pg_assoc_dev(h, n, c, -3, b, b, b, b, ok_ld, 0, b, b, b, b, b, b, None)),
+        ("pg_assoc_dev c = 0", lambda: L.pg_assoc_dev(h, n, 0, p, b, b, b, b, ok_ld, 0, b, b, b, b, b, b, None)),
+        ("pg_assoc_dev c = 31", lambda: L.pg_assoc_dev(h, n, 31, p, b, b, b, b, ok_ld, 0, b, b, b, b, b, b, None)),
+        ("pg_assoc_dev n - c - 1 = 0", lambda: L.pg_assoc_dev(h, 4, 3, p, b, b, b, b, ok_ld, 0, b, b, b, b, b, b, None)),
+        ("pg_assoc_dev NULL F", lambda: L.pg_assoc_dev(h, n, c, p, b, b, b, b, ok_ld, 0, b, b, b, b, None, b, None)),
+        ("pg_assoc_lrt_dev NULL D_lrt", lambda: L.pg_assoc_lrt_dev(h, n, c, p, b, b, b, b, ok_ld, 0, b, b, b, b, b, b, b, b, None, b)),
+        ("pg_assoc_lrt_dev c = 31", lambda: L.pg_assoc_lrt_dev(h, n, 31, p, b, b, b, b, ok_ld, 0, b, b, b, b, b, b, b, b, b, b)),
+        ("pg_fdist_sf_dev count < 0", lambda: L.pg_fdist_sf_dev(h, -1, b, 10.0, b)),
+        ("pg_memcpy2d_h2d_async pitch < width", lambda: L.pg_memcpy2d_h2d_async(h, b, 16, hp, 8, 16, 4)),
+        ("pg_stage_rows NULL dst", lambda: L.pg_stage_rows(None, 16, hp, 16, 16, 4, 1)),
+        ("pg_host_register 0 bytes", lambda: L.pg_host_register(h, hp, 0)),
+        ("pg_comm_broadcast_dev NULL comm", lambda: L.pg_comm_broadcast_dev(None, b, 16, 0)),
+        ("pg_comm_init_rank rank >= nranks", lambda: L.pg_comm_init_rank(h, 2, 2, hp, C.byref(C.c_void_p()))),
+        ("pg_ctx_create device out of range", lambda: L.pg_ctx_create(4096, C.byref(C.c_void_p()))),
+    ]
+    for name, call in bad:
+        rc = call()
+        assert rc < 0, (name, rc)
+        assert len(L.pg_last_error()) > 0, name
+    assert L.pg_assoc_dev(h, n, c, 0, b, b, b, b, ok_ld, 0, b, b, b, b, b, b, None) == 0      # an empty block is not an error
+    buf.free()
+    # the context still computes
+    rp = synth.rotated_panel(n, p, c, seed=3)
+    got = ops.assoc(rp["d"], rp["W"], rp["Y"], rp["X"], ctx=ctx)
+    assert np.isfinite(got["beta"]).all()
