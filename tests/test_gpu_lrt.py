@@ -76,3 +76,21 @@ def test_lrt_wide_covariate_counts_vs_oracle(n, p, c):
     base = lmm.pygemma(rp["Y"], rp["X"], rp["W"], rp["d"], eigen=False)
     for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
         assert (bits(df[col].to_numpy()) == bits(base[col].to_numpy())).all(), col
+
+
+def test_lrt_on_degenerate_panels_same_nan_rows_as_oracle():
+    """synth.degenerate_panels() with lrt=True: no exception, the oracle's NaN rows, l_alt / l_null within one float32 ulp of the
+    oracle in the kernels' order wherever finite (tools/adversarial_lrt.py prints the same per case)."""
+    from oracle import oracle as O
+    from pygemma import lmm
+    from pygemma_amd import synth
+    for tag, d, W, y, X in synth.degenerate_panels():
+        df = lmm.pygemma(y.reshape(-1, 1), X, W, d, eigen=False, lrt=True)
+        o = O.calculate_lrt(np.maximum(np.float32(0), d), y, W, X, order=1, nthreads=4)
+        for col in ("l_alt", "D_lrt", "p_lrt"):
+            a, b = df[col].to_numpy().astype(np.float64), np.asarray(o[col], np.float64)
+            assert (np.isnan(a) == np.isnan(b)).all(), (tag, col)
+        a, b = df["l_alt"].to_numpy().astype(np.float64), np.asarray(o["l_alt"], np.float64)
+        fin = np.isfinite(a) & np.isfinite(b)
+        assert (np.abs(a[fin] - b[fin]) <= np.spacing(np.abs(b[fin]).astype(np.float32))).all(), tag
+        assert (a[~fin & ~np.isnan(a)] == b[~fin & ~np.isnan(a)]).all(), tag           # infinities on the same rows, same sign
