@@ -263,9 +263,9 @@ def pinned_empty(shape, dtype=np.float32, device=0):
 
 
 def pin(arr, device=0):
-    """Page-lock an existing C-contiguous NumPy array in place (hipHostRegister).  Returns a handle whose .close() unpins;
-    pinning costs ~0.1 s/GB, so it pays for arrays that are streamed more than once — otherwise let lmm.pygemma stage."""
-    assert arr.flags.c_contiguous
+    """Page-lock an existing contiguous (C- or Fortran-ordered) NumPy array in place (hipHostRegister).  Returns a handle whose
+    .close() unpins; pinning costs ~5 ms/GB (tools/bench_h2d.py)."""
+    assert arr.flags.c_contiguous or arr.flags.f_contiguous
     ctx = Context(device)
     check(load().pg_host_register(ctx.handle, arr.ctypes.data, arr.nbytes), "pg_host_register")
     _pinned[arr.ctypes.data] = arr.nbytes

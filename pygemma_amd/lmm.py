@@ -166,6 +166,7 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
             bpr = (n + 3) // 4
             p = X.shape[1]
             direct = (not packed) and _lib.is_pinned(X)        # X itself is page-locked: DMA straight out of it
+            snp_major = (not packed) and X.flags.f_contiguous and not X.flags.c_contiguous     # (float32 only: pygemma() sees to it)
             nout = 32 + (32 if lrt else 0)                      # result bytes per SNP
             todo = []
             for s in range(a, b, pb_max):
@@ -193,6 +194,7 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                     try:
                         raw_bytes = pb_max * bpr if packed else n * ldX * esz
                         dX = ctx.alloc(raw_bytes)
+                        dT = ctx.alloc(pb_max * n * 4) if (snp_major and eigen) else None     # SNP-major batch on its way to sample-major
                         dXf = None       # float32 image of an 8-bit block, only if one does not qualify for the genotype path
                         dXr = ctx.alloc(pb_max * ldx * 4)
                         dres = ctx.alloc(pb_max * nout)
@@ -217,6 +219,16 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                 else:
                                     C.memmove(stg.inp, np.ascontiguousarray(rec).ctypes.data, pb * bpr)
                                 _lib.check(L.pg_memcpy_h2d_async(ctx.handle, dX.ptr, stg.inp, pb * bpr), "pg_memcpy_h2d_async")
+                            elif snp_major:    # SNPs [s, e) are pb contiguous rows of n floats
+                                src = X.ctypes.data + 4 * n * s
+                                dst, dpitch = (dT.ptr, 4 * n) if eigen else (dXr.ptr, 4 * ldx)       # eigen=False: already the layout the scan reads
+                                if direct:
+                                    _lib.check(L.pg_memcpy2d_h2d_async(ctx.handle, dst, dpitch, src, 4 * n, 4 * n, pb), "pg_memcpy2d_h2d_async")
+                                else:
+                                    _lib.check(L.pg_stage_rows(stg.inp, 4 * n, src, 4 * n, 4 * n, pb, _STAGE_THREADS), "pg_stage_rows")
+                                    _lib.check(L.pg_memcpy2d_h2d_async(ctx.handle, dst, dpitch, stg.inp, 4 * n, 4 * n, pb), "pg_memcpy2d_h2d_async")
+                                if eigen:      # (pb x n) -> (n x ldX): the transposition kernel with the roles of n and p exchanged
+                                    _lib.check(L.pg_transpose_dev(ctx.handle, pb, n, dT.ptr, n, dX.ptr, ldX), "pg_transpose_dev")
                             else:
                                 src = X.ctypes.data + esz * s
                                 if direct:
@@ -248,7 +260,7 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                 elif eigen:      # float32 block: path (genotype fp16x2 / split planes / fp32 MFMA) chosen on the device, no host wait
                                     _lib.check(L.pg_rotate_auto_dev(ctx.handle, n, pb, dU.ptr, n, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx,
                                                                     dwork.ptr, None), "pg_rotate_auto_dev")
-                                else:
+                                elif not snp_major:
                                     _lib.check(L.pg_transpose_dev(ctx.handle, n, pb, dX.ptr, ldX, dXr.ptr, ldx), "pg_transpose_dev")
                                 # result block: [F | p | beta | se | tau | lambda] (+ [l_alt | l_null | D_lrt | p_lrt] f64 with lrt)
                                 r0 = dres.ptr
@@ -394,7 +406,10 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
         k64 = eigen and K.dtype == np.float64                # rounded to float32 on the device instead (same values, no host copy)
         if K.dtype != np.float32 and not k64:
             K = K.astype(np.float32)                         # lmm.py:127-128
-    if not packed and not X.flags.c_contiguous:
+    # A Fortran-ordered float32 X is the SNP-major image (p rows of n samples): its batches are contiguous byte ranges that go to the
+    # device as they are (and are turned sample-major there when they have to be rotated) — no transposing host copy of the matrix
+    snp_major = (not packed) and X.ndim == 2 and X.dtype == np.float32 and X.flags.f_contiguous and not X.flags.c_contiguous
+    if not packed and not X.flags.c_contiguous and not snp_major:
         X = np.ascontiguousarray(X)
     n, p = X.shape
     c = W.shape[1]

@@ -195,3 +195,37 @@ def test_two_gpus_equal_one_gpu_bit_for_bit():
     b = lmm.pygemma(rp["Y"], rp["X"], rp["W"], rp["d"], eigen=False, nproc=2)
     for col in COLS:
         assert (bits(a[col].to_numpy()) == bits(b[col].to_numpy())).all(), col
+
+
+@pytest.mark.parametrize("eigen", [True, False])
+@pytest.mark.parametrize("how", ["pageable", "pinned", "staged"])
+def test_fortran_ordered_snp_major_X_streams_without_a_host_transpose(eigen, how, monkeypatch):
+    """A Fortran-ordered float32 X (the SNP-major image: what np.fromfile(...).reshape(p, n).T is) goes to the device batch by
+    batch as contiguous rows — turned sample-major on the device for the rotation, used as it is on the eigen=False entry — and
+    gives the rows of the C-ordered matrix bit for bit, whether X is pageable (page-locked in place), pinned, or staged."""
+    from pygemma_amd import lmm, synth, _lib
+    n, p, c = 333, 700, 3
+    monkeypatch.setattr(lmm, "_BATCH_SNPS", 256)                 # several ragged batches
+    if eigen:
+        raw = synth.panel(n, p, c, seed=21)
+        Y, Xc, W, K = raw["Y"], np.ascontiguousarray(raw["X"]), raw["W"], raw["K"]
+    else:
+        rp = synth.rotated_panel(n, p, c, seed=21)
+        Y, Xc, W, K = rp["Y"], np.ascontiguousarray(rp["X"]), rp["W"], rp["d"]
+    ref = lmm.pygemma(Y, Xc, W, K, eigen=eigen)
+    if how == "pinned":
+        buf = lmm.pinned_empty((p, n), np.float32); buf[:] = Xc.T
+        Xf = buf.T
+    else:
+        Xf = np.asfortranarray(Xc)
+    assert Xf.flags.f_contiguous and not Xf.flags.c_contiguous and Xf.shape == (n, p)
+    if how == "staged":
+        def refuse(arr, device=0):
+            raise _lib.PgError("registration refused (test)")
+        monkeypatch.setattr(_lib, "pin", refuse)
+    st = {}
+    got = lmm.pygemma(Y, Xf, W, K, eigen=eigen, stats=st)
+    assert st["batches"] >= 3 and st["pinned_input"] == (how != "staged")
+    for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
+        a, b = got[col].to_numpy(), ref[col].to_numpy()
+        assert (a.view(np.uint8) == b.view(np.uint8)).all(), col
