@@ -150,7 +150,8 @@ def main():
     rank, world, local_rank = dist.env_rank()
     if a.gpus != world:
         log(rank, f"note: --gpus {a.gpus} but WORLD_SIZE={world}; using the launcher's world size")
-    n, c, B, P = a.n, a.c, a.batch, a.snps
+    n, c, P = a.n, a.c, a.snps
+    B = max(1, min(a.batch, P))       # a batch is never larger than the step
     L = _lib.load()
     if _lib.device_count() < 1:
         raise SystemExit("no GPU visible: the MI355X path has no CPU fallback")
