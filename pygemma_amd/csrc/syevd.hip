@@ -569,19 +569,33 @@ __global__ __launch_bounds__(256) void zhat_kernel(int k, const double *dl, cons
 
 // U[:, j] = (zh_i / Dm[i][j])_i, normalised; in place over Dm.  64 columns per workgroup (coalesced across j), the rows
 // split over the 4 waves, column norms combined through LDS in a fixed order.
-__global__ __launch_bounds__(256) void uvec_kernel(int k, const double *zh, const int *rp, double *Dm)
+// Two launches, rows cut into chunks of UV_ROWS so that a merge of k = 7 000 poles fills the chip (110 workgroups of the one-kernel
+// version left 60 % of the CUs idle, each thread walking 1 750 dependent load + divide steps twice: 18 ms per solve, now ~2):
+// (1) sums of squares of a chunk's rows per column -> part[chunk][j]; (2) the chunks' sums added in chunk order, rows scaled.
+constexpr int UV_ROWS = 256;
+__global__ __launch_bounds__(256) void uvec_norm_kernel(int k, const double *zh, const int *rp, const double *Dm, double *part)
 {
-    __shared__ double part[4][64];
+    __shared__ double sh[4][64];
     const int jj = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + jj;
+    const int i0 = blockIdx.y * UV_ROWS, i1 = (i0 + UV_ROWS < k) ? i0 + UV_ROWS : k;
     double ss = 0.0;
     if (j < k)
-        for (int i = rg; i < k; i += 4) { const double v = zh[i] / Dm[(size_t)rp[i] * k + j]; ss += v * v; }
-    part[rg][jj] = ss;
+        for (int i = i0 + rg; i < i1; i += 4) { const double v = zh[i] / Dm[(size_t)rp[i] * k + j]; ss += v * v; }
+    sh[rg][jj] = ss;
     __syncthreads();
+    if (rg == 0 && j < k) part[(size_t)blockIdx.y * k + j] = ((sh[0][jj] + sh[1][jj]) + sh[2][jj]) + sh[3][jj];
+}
+__global__ __launch_bounds__(256) void uvec_scale_kernel(int k, const double *zh, const int *rp, double *Dm, const double *part, int nchunk)
+{
+    const int jj = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jj;
     if (j >= k) return;
-    const double inv = 1.0 / sqrt(((part[0][jj] + part[1][jj]) + part[2][jj]) + part[3][jj]);
-    for (int i = rg; i < k; i += 4) { const size_t at = (size_t)rp[i] * k + j; const double v = zh[i] / Dm[at]; Dm[at] = v * inv; }
+    double ss = 0.0;
+    for (int c = 0; c < nchunk; c++) ss += part[(size_t)c * k + j];
+    const double inv = 1.0 / sqrt(ss);
+    const int i0 = blockIdx.y * UV_ROWS, i1 = (i0 + UV_ROWS < k) ? i0 + UV_ROWS : k;
+    for (int i = i0 + rg; i < i1; i += 4) { const size_t at = (size_t)rp[i] * k + j; const double v = zh[i] / Dm[at]; Dm[at] = v * inv; }
 }
 
 __global__ void copy_block_kernel(int n, int r0, int nm, const double *Qin, double *Qout)
@@ -667,7 +681,7 @@ static void plan_merge(MergePlan &mp, const double *d_in, const double *z_in, do
 }
 
 struct StedcWork {
-    double *Qa = nullptr, *Qb = nullptr, *Tp = nullptr, *Um = nullptr, *z = nullptr, *dnew = nullptr, *dl = nullptr, *w = nullptr, *zh = nullptr, *S = nullptr;
+    double *Qa = nullptr, *Qb = nullptr, *Tp = nullptr, *Um = nullptr, *z = nullptr, *dnew = nullptr, *dl = nullptr, *w = nullptr, *zh = nullptr, *S = nullptr, *unorm = nullptr;
     int *ibuf = nullptr;   // zrow | col | leaf tables
     Rot *rots = nullptr;
 };
@@ -757,6 +771,7 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
         gather_z_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, Qin, wk.ibuf, wk.z);
         PG_HIP(hipMemcpyAsync(zhost.data(), wk.z, (size_t)n * 8, hipMemcpyDeviceToHost, st));
         PG_HIP(hipStreamSynchronize(st));
+        mark("  gather z", nb, 0);
         size_t rot_total = 0;
         for (auto &mp : plans) {
             plan_merge(mp, d.data() + mp.s, zhost.data() + mp.s, e[mp.s + mp.n1 - 1]);
@@ -775,6 +790,7 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
         if (!allrots.empty()) PG_HIP(hipMemcpyAsync(wk.rots, allrots.data(), allrots.size() * sizeof(Rot), hipMemcpyHostToDevice, st));
         PG_HIP(hipMemcpyAsync(wk.dl, dlw.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
         PG_HIP(hipMemcpyAsync(wk.w, dlw.data() + n, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        mark("  plan+copy", nb, 0);
         size_t roff = 0;
         for (auto &mp : plans) {
             const int nm = mp.nm, k = mp.k, s = mp.s;
@@ -787,7 +803,11 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
                 const int *rp = wk.ibuf + 2 * n + s;
                 secular_kernel<<<(k + 3) / 4, 256, 0, st>>>(k, wk.dl + s, wk.w + s, mp.rho, rp, wk.Um, wk.dnew + s);
                 zhat_kernel<<<(k + 3) / 4, 256, 0, st>>>(k, wk.dl + s, wk.w + s, rp, wk.Um, wk.zh);
-                uvec_kernel<<<(k + 63) / 64, 256, 0, st>>>(k, wk.zh, rp, wk.Um);
+                {
+                    const int nchunk = (k + UV_ROWS - 1) / UV_ROWS;
+                    uvec_norm_kernel<<<dim3((k + 63) / 64, nchunk), 256, 0, st>>>(k, wk.zh, rp, wk.Um, wk.unorm);
+                    uvec_scale_kernel<<<dim3((k + 63) / 64, nchunk), 256, 0, st>>>(k, wk.zh, rp, wk.Um, wk.unorm, nchunk);
+                }
                 // Q_new = [Q1 0; 0 Q2] U: the upper rows only meet the columns of types 1, 2 (slots [0, k1+k2)), the lower rows
                 // those of types 2, 3 (slots [k1, k))
                 const int n1 = mp.n1, n2 = nm - mp.n1, k12 = mp.k1 + mp.k2, k23 = k - mp.k1;
@@ -837,16 +857,17 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
 static int stedc_alloc(int n, StedcWork &wk)
 {
     int rc = PG_OK;
-    double **bufs[] = {&wk.Qa, &wk.Qb, &wk.Tp, &wk.Um, &wk.z, &wk.dnew, &wk.dl, &wk.w, &wk.zh, &wk.S};
-    size_t sizes[] = {(size_t)n * n, (size_t)n * n, (size_t)n * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)n, (size_t)n, (size_t)n * (DC_LEAF + 1)};
-    for (int k = 0; k < 10 && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
+    double **bufs[] = {&wk.Qa, &wk.Qb, &wk.Tp, &wk.Um, &wk.z, &wk.dnew, &wk.dl, &wk.w, &wk.zh, &wk.S, &wk.unorm};
+    size_t sizes[] = {(size_t)n * n, (size_t)n * n, (size_t)n * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)n, (size_t)n, (size_t)n * (DC_LEAF + 1),
+                      ((size_t)n / UV_ROWS + 2) * n};
+    for (int k = 0; k < 11 && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
     if (!rc && hipMalloc(&wk.ibuf, (3 * (size_t)n + 16) * 4) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
     if (!rc && hipMalloc(&wk.rots, ((size_t)n + 1) * sizeof(Rot)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
     return rc;
 }
 static void stedc_free(StedcWork &wk)
 {
-    for (double *p : {wk.Qa, wk.Qb, wk.Tp, wk.Um, wk.z, wk.dnew, wk.dl, wk.w, wk.zh, wk.S}) if (p) (void)hipFree(p);
+    for (double *p : {wk.Qa, wk.Qb, wk.Tp, wk.Um, wk.z, wk.dnew, wk.dl, wk.w, wk.zh, wk.S, wk.unorm}) if (p) (void)hipFree(p);
     if (wk.ibuf) (void)hipFree(wk.ibuf);
     if (wk.rots) (void)hipFree(wk.rots);
     wk = StedcWork{};
@@ -919,7 +940,10 @@ extern "C" int pgx_stedc_dev(pg_ctx *ctx, int64_t n64, const double *d_host, con
 // Back-transformation block: BB reflectors = BB/NB sub-blocks of NB.  T (BB x BB, upper triangular, compact WY:
 // H_0 .. H_{m-1} = I - V T V') is built from the Gram matrix G = V'V: the NB x NB diagonal blocks by the dlarft
 // recurrence (one workgroup per sub-block), the off-diagonal block columns by T(0:r, r:r+w) = -T(0:r,0:r) G(0:r, r:r+w) T(r:r+w, r:r+w).
-constexpr int BB = 256;
+#ifndef PG_BT_BLOCK
+#define PG_BT_BLOCK 256
+#endif
+constexpr int BB = PG_BT_BLOCK;
 __global__ __launch_bounds__(64) void larft_kernel(int m, const double *G, const double *tau, double *T)
 {
     __shared__ double Ts[NB][NB + 1];
