@@ -87,12 +87,16 @@ __device__ __forceinline__ double vval(const double *acol, double scal, int i, i
 //                     workgroups, the 2*ci panel dot products W[c,:].v, V[c,:].v
 //   w_update_kernel : w = tau (y - V t1 - W t2), partial sums of w.v; stores v into the panel, Vall and vcur
 // P = [V ; W ; V] stacked (3*NB x n), panel column c of V at P[c*n + r], of W at P[(NB+c)*n + r]
-__global__ __launch_bounds__(256) void col_kernel(int n, int i, int ci, int nblk_prev, const double *A, double *P, const double *vprev,
+#ifndef PG_COL_CG
+#define PG_COL_CG 8       // (4: 465 ms of tridiagonalisation at n = 10 000, 8: 460, 16: 463)
+#endif
+__global__ __launch_bounds__(64 * PG_COL_CG) void col_kernel(int n, int i, int ci, int nblk_prev, const double *A, double *P, const double *vprev,
                                                   const double *wtmp, const double *tauvec, const double *wvpart, double *acol, double *normpart)
 {
-    // 64 rows per workgroup, the panel columns split 4 ways over the waves (short latency chains, 4x the workgroups)
-    __shared__ double part[4][64];
-    __shared__ double sh[4];
+    // 64 rows per workgroup, the panel columns split CG ways over the waves (short latency chains)
+    constexpr int CG = PG_COL_CG;
+    __shared__ double part[CG][64];
+    __shared__ double sh[CG];
     const int rr = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int r = i + blockIdx.x * 64 + rr;
     double *V = P, *W = P + (size_t)NB * n;
@@ -105,13 +109,16 @@ __global__ __launch_bounds__(256) void col_kernel(int n, int i, int ci, int nblk
     double acc = 0.0;
     if (r < n) {
 #pragma unroll 4
-        for (int c = cg; c + 1 < ci; c += 4) acc -= V[(size_t)c * n + r] * W[(size_t)c * n + i] + W[(size_t)c * n + r] * V[(size_t)c * n + i];
+        for (int c = cg; c + 1 < ci; c += CG) acc -= V[(size_t)c * n + r] * W[(size_t)c * n + i] + W[(size_t)c * n + r] * V[(size_t)c * n + i];
     }
     part[cg][rr] = acc;
     __syncthreads();
     double sq = 0.0;
     if (cg == 0 && r < n) {
-        acc = A[(size_t)r * n + i] + (((part[0][rr] + part[1][rr]) + part[2][rr]) + part[3][rr]);
+        double ps = part[0][rr];
+#pragma unroll
+        for (int g = 1; g < CG; g++) ps += part[g][rr];
+        acc = A[(size_t)r * n + i] + ps;
         if (ci > 0) {
             const int c = ci - 1;
             const double wr = wtmp[r] + alpha * vprev[r];
@@ -250,13 +257,16 @@ __global__ __launch_bounds__(256, PG_SYMV_OCC) void symv_sym_kernel(int n, int i
     }
 }
 
-template <bool SYM>
-__global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, int nbr, double *P, const double *acol, const double *hh, const double *y,
+#ifndef PG_WUPD_CG
+#define PG_WUPD_CG 16      // waves per 64-row block of the w update, each taking every CG-th panel column / partial sum (4 -> 16: 471 -> 457 ms of tridiagonalisation at n = 10 000; 148 workgroups of 4 waves left the loads un-hidden)
+#endif
+template <bool SYM, int CG = PG_WUPD_CG>
+__global__ __launch_bounds__(64 * CG) void w_update_kernel(int n, int i, int ci, int nbr, double *P, const double *acol, const double *hh, const double *y,
                                                        const double *rowpart, const double *colpart, const double *t,
                                                        double *Vall, double *vcur, double *wtmp, double *partial)
 {
-    __shared__ double part[4][64];
-    __shared__ double sh[4];
+    __shared__ double part[CG][64];
+    __shared__ double sh[CG];
     const int rr = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int r = i + 1 + blockIdx.x * 64 + rr;
     const double *V = P, *W = P + (size_t)NB * n;
@@ -264,19 +274,19 @@ __global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, int
     double acc = 0.0;
     if (r < n) {
 #pragma unroll 4
-        for (int c = cg; c < ci; c += 4) acc -= V[(size_t)c * n + r] * t[c] + W[(size_t)c * n + r] * t[ci + c];
+        for (int c = cg; c < ci; c += CG) acc -= V[(size_t)c * n + r] * t[c] + W[(size_t)c * n + r] * t[ci + c];
         if (SYM) {
             // (A v)_r from the symmetric partials, split over the 4 waves, each in a fixed order
             const int s = i + 1, cb = s & ~1, delta = s - cb;
             const int Ir = (r - s) >> 6, nJ = (64 * Ir + 63 + delta) / 128 + 1;
             double ya = 0.0;
 #pragma unroll 8
-            for (int J = cg; J < nJ; J += 4) ya += rowpart[(size_t)J * n + r];
+            for (int J = cg; J < nJ; J += CG) ya += rowpart[(size_t)J * n + r];
             const int Jc = (r - cb) >> 7;
             int Imin = (128 * Jc - delta) / 64;
             if (Jc == 0) Imin = 0;
 #pragma unroll 8
-            for (int I = Imin + cg; I < nbr; I += 4) ya += colpart[(size_t)I * n + r];
+            for (int I = Imin + cg; I < nbr; I += CG) ya += colpart[(size_t)I * n + r];
             acc += ya;
         }
     }
@@ -284,7 +294,10 @@ __global__ __launch_bounds__(256) void w_update_kernel(int n, int i, int ci, int
     __syncthreads();
     double wv = 0.0;
     if (cg == 0 && r < n) {
-        acc = (SYM ? 0.0 : y[r]) + (((part[0][rr] + part[1][rr]) + part[2][rr]) + part[3][rr]);
+        double ps = part[0][rr];
+#pragma unroll
+        for (int g = 1; g < CG; g++) ps += part[g][rr];
+        acc = (SYM ? 0.0 : y[r]) + ps;
         acc *= tau;
         wtmp[r] = acc;
         const double v = vval(acol, scal, i, r);       // the reflector, stored here for everything downstream
@@ -333,7 +346,7 @@ static int sytrd_device(pg_ctx *ctx, int n, SytrdWork &w)
         for (int ci = 0; ci < nbc; ci++) {
             const int i = i0 + ci;
             const int nblk_col = (n - i + 63) / 64;
-            col_kernel<<<nblk_col, 256, 0, s>>>(n, i, ci, nblk_prev, w.A, w.P, w.vcur, w.wtmp, w.tau, w.partial, w.acol, normpart);
+            col_kernel<<<nblk_col, 64 * PG_COL_CG, 0, s>>>(n, i, ci, nblk_prev, w.A, w.P, w.vcur, w.wtmp, w.tau, w.partial, w.acol, normpart);
             double *hh = w.t + 2 * NB;
             const int nt = n - i - 1;
             const int nblk = (nt + 63) / 64;
@@ -341,11 +354,11 @@ static int sytrd_device(pg_ctx *ctx, int n, SytrdWork &w)
                 const int nbr = nblk, ywaves = (64 * (nbr - 1) + 64) / 128 + 1;
                 symv_sym_kernel<<<dim3(nbr + 2 * ci, (ywaves + 3) / 4), 256, 0, s>>>(n, i, ci, nbr, w.A, w.P, w.acol, normpart, nblk_col, hh, w.d, w.e, w.tau,
                                                                                   w.rowpart, w.colpart, w.t);
-                w_update_kernel<true><<<nblk, 256, 0, s>>>(n, i, ci, nbr, w.P, w.acol, hh, w.y, w.rowpart, w.colpart, w.t, w.Vall, w.vcur, w.wtmp, w.partial);
+                w_update_kernel<true><<<nblk, 64 * PG_WUPD_CG, 0, s>>>(n, i, ci, nbr, w.P, w.acol, hh, w.y, w.rowpart, w.colpart, w.t, w.Vall, w.vcur, w.wtmp, w.partial);
             } else {
                 const int nsymv = (nt + 3) / 4;
                 symv_dots_kernel<<<nsymv + 2 * ci, 256, 0, s>>>(n, i, ci, nsymv, w.A, w.P, w.acol, normpart, nblk_col, hh, w.d, w.e, w.tau, w.y, w.t);
-                w_update_kernel<false><<<nblk, 256, 0, s>>>(n, i, ci, nblk, w.P, w.acol, hh, w.y, w.rowpart, w.colpart, w.t, w.Vall, w.vcur, w.wtmp, w.partial);
+                w_update_kernel<false><<<nblk, 64 * PG_WUPD_CG, 0, s>>>(n, i, ci, nblk, w.P, w.acol, hh, w.y, w.rowpart, w.colpart, w.t, w.Vall, w.vcur, w.wtmp, w.partial);
             }
             nblk_prev = nblk;
             if (ci == nbc - 1) w_final_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, i, ci, nblk, w.P, w.vcur, w.wtmp, w.tau, w.partial);
@@ -363,7 +376,7 @@ static int sytrd_device(pg_ctx *ctx, int n, SytrdWork &w)
     }
     // last diagonal entry
     PG_HIP(hipMemsetAsync(w.P, 0, (size_t)3 * NB * n * sizeof(double), s));
-    col_kernel<<<1, 256, 0, s>>>(n, n - 1, 0, 0, w.A, w.P, w.vcur, w.wtmp, w.tau, w.partial, w.acol, w.partial + (n / 64 + 2));
+    col_kernel<<<1, 64 * PG_COL_CG, 0, s>>>(n, n - 1, 0, 0, w.A, w.P, w.vcur, w.wtmp, w.tau, w.partial, w.acol, w.partial + (n / 64 + 2));
     PG_HIP(hipMemcpyAsync(w.d + (n - 1), w.acol + (n - 1), sizeof(double), hipMemcpyDeviceToDevice, s));
     PG_HIP(hipGetLastError());
     return PG_OK;
