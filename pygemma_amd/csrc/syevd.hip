@@ -962,14 +962,16 @@ __global__ __launch_bounds__(64) void larft_kernel(int m, const double *G, const
     __shared__ double Ts[NB][NB + 1];
     const int off = blockIdx.x * NB, mb = (m - off < NB) ? m - off : NB;
     G += (size_t)off * BB + off; T += (size_t)off * BB + off; tau += off;
+    __shared__ double Gs[NB][NB + 1];          // the sub-block of G: the recurrence below walks its columns, 64 dependent steps
     const int i = threadIdx.x;
     for (int j = 0; j < NB; j++) if (i < NB) Ts[i][j] = 0.0;
+    for (int l = 0; l < mb; l++) if (i < mb) Gs[l][i] = G[(size_t)l * BB + i];     // row l, coalesced over i
     __syncthreads();
     for (int j = 0; j < mb; j++) {
         const double tj = tau[j];
         double v = 0.0;
         if (i < j) {
-            for (int l = i; l < j; l++) v += Ts[i][l] * G[(size_t)l * BB + j];
+            for (int l = i; l < j; l++) v += Ts[i][l] * Gs[l][j];
             v *= -tj;
         }
         __syncthreads();
