@@ -1,3 +1,5 @@
+#!/bin/bash
+# bench.py at a list of resident batch sizes (BATCHES="16384 100000 ..."): step time, rotation and association time per launch.
 cd $GRAFT_REPO_ROOT
 python3 bench.py --steps 1 --warmup 0 --e2e 0 --cpu-sample 0 --eigh-cache /tmp/eig.npz > /dev/null 2>&1
 for b in ${BATCHES:-16384 25000 33334 50000 100000 16384}; do
