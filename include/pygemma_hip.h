@@ -48,6 +48,7 @@ int pg_ctx_device(const pg_ctx *ctx);
 /* device memory helpers for callers without their own allocator (Python/ctypes hosts) */
 int pg_malloc(pg_ctx *ctx, size_t bytes, void **dptr);
 int pg_free(pg_ctx *ctx, void *dptr);
+int pg_mem_info(pg_ctx *ctx, size_t *free_bytes, size_t *total_bytes);   /* of ctx's device (how much of X may be prefetched) */
 int pg_memcpy_h2d(pg_ctx *ctx, void *dst, const void *src, size_t bytes);
 int pg_memcpy_d2h(pg_ctx *ctx, void *dst, const void *src, size_t bytes);
 int pg_memset(pg_ctx *ctx, void *dst, int value, size_t bytes);

@@ -14,7 +14,7 @@ _lib = None
 
 SYMBOLS = [
     "pg_last_error", "pg_version", "pg_device_count", "pg_ctx_create", "pg_ctx_create_on_stream",
-    "pg_ctx_destroy", "pg_ctx_sync", "pg_ctx_device", "pg_malloc", "pg_free", "pg_memcpy_h2d", "pg_memcpy_d2h",
+    "pg_ctx_destroy", "pg_ctx_sync", "pg_ctx_device", "pg_mem_info", "pg_malloc", "pg_free", "pg_memcpy_h2d", "pg_memcpy_d2h",
     "pg_memset", "pg_memcpy2d_h2d", "pg_event_create", "pg_event_destroy", "pg_event_record", "pg_event_elapsed_ms",
     "pg_kinship_dev", "pg_geno_prep_bytes", "pg_geno_work_bytes", "pg_geno_prep_dev", "pg_rotate_geno_dev", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev", "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev",
     "pg_precompute_mat_dev", "pg_newton_dev", "pg_reml_scalars_dev", "pg_rotate_bed_dev", "pg_rotate_geno_i8_dev", "pg_cast_i8_f32_dev", "pg_assoc_multi", "pg_rotate_geno_f64_dev", "pg_cast_f64_f32_dev",
@@ -49,6 +49,7 @@ def load():
     L.pg_ctx_destroy.restype = None
     L.pg_ctx_sync.argtypes = [vp]
     L.pg_ctx_device.argtypes = [vp]
+    L.pg_mem_info.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.pg_malloc.argtypes = [vp, sz, C.POINTER(vp)]
     L.pg_free.argtypes = [vp, vp]
     L.pg_memcpy_h2d.argtypes = [vp, vp, vp, sz]
@@ -196,6 +197,12 @@ class Context:
 
     def sync(self):
         check(load().pg_ctx_sync(self.handle), "pg_ctx_sync")
+
+    def mem_info(self):
+        """(free, total) bytes of this context's device."""
+        f, t = C.c_size_t(), C.c_size_t()
+        check(load().pg_mem_info(self.handle, C.byref(f), C.byref(t)), "pg_mem_info")
+        return int(f.value), int(t.value)
 
     def close(self):
         if self.handle:

@@ -183,6 +183,14 @@ extern "C" int pg_ctx_sync(pg_ctx *ctx)
 }
 extern "C" int pg_ctx_device(const pg_ctx *ctx) { return ctx ? ctx->device : -1; }
 
+extern "C" int pg_mem_info(pg_ctx *ctx, size_t *free_bytes, size_t *total_bytes)
+{
+    PG_REQUIRE(ctx && free_bytes && total_bytes, "pg_mem_info: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
+    PG_HIP(hipMemGetInfo(free_bytes, total_bytes));
+    return PG_OK;
+}
+
 extern "C" int pg_malloc(pg_ctx *ctx, size_t bytes, void **dptr)
 {
     PG_REQUIRE(ctx && dptr, "pg_malloc: NULL argument");

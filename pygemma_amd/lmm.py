@@ -47,6 +47,8 @@ _BATCH_MIN = 8192        # ... and at least, while the block is cut into up to _
 _BATCH_COUNT = 12        # last batch's kernels are the part of the loop that does not overlap (measured at p = 100 000: 4 batches
                          # 0.149-0.172 s, 8: 0.116, 12: 0.112, 16: 0.112 — tools/ab_stream_batch.py)
 _STAGE_THREADS = 8       # host copy threads per worker for the pageable -> pinned leg
+_PREFETCH_MAX = 96 << 30     # device bytes of X per GPU that may be copied in while the eigensolver runs
+_PREFETCH_MARGIN = 8 << 30  # ... and what is left untouched beside the eigensolver's and the workers' buffers
 
 
 class SampleIter:
@@ -127,7 +129,78 @@ class _Staging:
         self.inp = self.out = None
 
 
-def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out, errs, verbose, ckpt=None, stats=None):
+def _batch_geometry(n, a, b):
+    """(SNPs per batch, row pitch in elements of a raw sample-major batch) for the block [a, b) of one GPU."""
+    ldx = (n + 63) // 64 * 64
+    pb_max = max(256, int(_BATCH_BYTES // (12 * ldx)) // 256 * 256)   # raw block + rotated block + two fp16 planes
+    pb_max = min(pb_max, _BATCH_SNPS, b - a)
+    nbat = max(-(-(b - a) // pb_max), min(_BATCH_COUNT, -(-(b - a) // _BATCH_MIN)))
+    pb_max = min(pb_max, (-(-(b - a) // nbat) + 255) // 256 * 256)
+    return pb_max, (pb_max + 15) // 16 * 16
+
+
+class _Prefetch:
+    """X on its way to the devices WHILE the eigensolver runs (eigen=True from K; X a C-contiguous, page-locked host matrix): one
+    host thread per GPU DMAs the leading batches of that GPU's block into device buffers on a stream of its own — PCIe and the
+    HBM-bound tridiagonalisation do not compete — within what hipMemGetInfo leaves after the eigensolver's workspace (~60 n^2
+    bytes on GPU 0) and the workers' own buffers.  The SNP loop then takes those buffers instead of issuing the copies: at
+    p = 100 000 the loop drops from 0.11 to the kernels' 0.07 s, at 288 GB of HBM a 40 GB float32 X is resident before U is."""
+
+    def __init__(self, L, X, blocks, n, esz, verbose):
+        self.L, self.X, self.n, self.esz, self.verbose = L, X, n, esz, verbose
+        self.lock = threading.Lock()
+        self.bufs = [dict() for _ in blocks]
+        self.ctxs = [None] * len(blocks)
+        self.bytes = 0
+        self.stop = False                        # set when the eigensolver is done: the batch in flight is the last one
+        self.threads = [threading.Thread(target=self._run, args=(g, a, b)) for g, (a, b) in enumerate(blocks)]
+        for th in self.threads:
+            th.start()
+
+    def _run(self, g, a, b):
+        try:
+            n, esz, p = self.n, self.esz, self.X.shape[1]
+            ctx = self.ctxs[g] = _lib.Context(g)
+            free, _total = ctx.mem_info()
+            reserve = (72 * n * n if g == 0 else 12 * n * n) + 2 * _BATCH_BYTES + _PREFETCH_MARGIN
+            budget = min(free - reserve, _PREFETCH_MAX)
+            pb_max, ldX = _batch_geometry(n, a, b)
+            used = 0
+            for s in range(a, b, pb_max):
+                e = min(s + pb_max, b)
+                nbytes = n * ldX * esz
+                if used + nbytes > budget or self.stop:
+                    break
+                buf = ctx.alloc(nbytes)
+                _lib.check(self.L.pg_memcpy2d_h2d_async(ctx.handle, buf.ptr, ldX * esz, self.X.ctypes.data + esz * s, p * esz, (e - s) * esz, n),
+                           "pg_memcpy2d_h2d_async")
+                ctx.sync()                       # a batch is offered only once it has landed
+                with self.lock:
+                    self.bufs[g][(s, e)] = buf
+                    self.bytes += n * (e - s) * esz
+                used += nbytes
+            _log(self.verbose, f"GPU {g}: {used / 1e9:.2f} GB of X prefetched during the eigendecomposition")
+        except Exception as ex:                  # prefetching is an optimisation: on any failure the loop copies as usual
+            _log(self.verbose, f"GPU {g}: prefetch stopped ({ex!r})")
+
+    def join(self):
+        self.stop = True
+        for th in self.threads:
+            th.join()
+
+    def take(self, g, s, e):
+        with self.lock:
+            return self.bufs[g].pop((s, e), None)
+
+    def close(self):
+        self.join()
+        for g, ctx in enumerate(self.ctxs):
+            if ctx is not None:
+                ctx.close()                      # frees what was not taken
+        self.ctxs = [None] * len(self.ctxs)
+
+
+def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out, errs, verbose, ckpt=None, stats=None, pre=None):
     """One GPU: SNP columns [a,b) of X through (rotate | transpose) -> assoc, in batches.  Two host threads per GPU, each with
     its own stream, device buffers and pinned staging, take batches from a shared list, so that the host->device DMA of one
     batch overlaps the kernels of the other.  `dU`: GPU 0's resident eigenvectors (device 0) or None; with a communicator the
@@ -158,11 +231,7 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
             x8 = (not packed) and X.dtype in (np.int8, np.uint8)
             x64 = (not packed) and X.dtype == np.float64
             esz = 1 if x8 else (8 if x64 else 4)
-            pb_max = max(256, int(_BATCH_BYTES // (12 * ldx)) // 256 * 256)   # raw block + rotated block + two fp16 planes
-            pb_max = min(pb_max, _BATCH_SNPS, b - a)
-            nbat = max(-(-(b - a) // pb_max), min(_BATCH_COUNT, -(-(b - a) // _BATCH_MIN)))
-            pb_max = min(pb_max, (-(-(b - a) // nbat) + 255) // 256 * 256)
-            ldX = (pb_max + 15) // 16 * 16
+            pb_max, ldX = _batch_geometry(n, a, b)
             bpr = (n + 3) // 4
             p = X.shape[1]
             direct = (not packed) and _lib.is_pinned(X)        # X itself is page-locked: DMA straight out of it
@@ -211,6 +280,7 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                 s, e = todo.pop(0)
                             pb = e - s
                             t_in = time.time()
+                            pbuf, dXc = None, dX     # dXc: where this batch's raw block is
                             # ---- the raw block travels to the device on this worker's stream
                             if packed:   # SNP records [s, e) of the .bed image: contiguous bytes
                                 rec = X.data[s:e]
@@ -229,6 +299,8 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                     _lib.check(L.pg_memcpy2d_h2d_async(ctx.handle, dst, dpitch, stg.inp, 4 * n, 4 * n, pb), "pg_memcpy2d_h2d_async")
                                 if eigen:      # (pb x n) -> (n x ldX): the transposition kernel with the roles of n and p exchanged
                                     _lib.check(L.pg_transpose_dev(ctx.handle, pb, n, dT.ptr, n, dX.ptr, ldX), "pg_transpose_dev")
+                            elif pre is not None and (pbuf := pre.take(device, s, e)) is not None:
+                                dXc = pbuf       # landed on the device while the eigensolver ran
                             else:
                                 src = X.ctypes.data + esz * s
                                 if direct:
@@ -248,20 +320,20 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                                                    dwork.ptr), "pg_rotate_bed_dev")
                                 elif x64:
                                     is_geno = C.c_int(0)
-                                    _lib.check(L.pg_rotate_geno_f64_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx, dwork.ptr,
+                                    _lib.check(L.pg_rotate_geno_f64_dev(ctx.handle, n, pb, dprep.ptr, dXc.ptr, ldX, dXr.ptr, ldx, dwork.ptr,
                                                                         C.byref(is_geno)), "pg_rotate_geno_f64_dev")
                                     if not is_geno.value:
                                         dXf = dXf or ctx.alloc(n * ldX * 4)
-                                        _lib.check(L.pg_cast_f64_f32_dev(ctx.handle, n, pb, dX.ptr, ldX, dXf.ptr, ldX), "pg_cast_f64_f32_dev")
+                                        _lib.check(L.pg_cast_f64_f32_dev(ctx.handle, n, pb, dXc.ptr, ldX, dXf.ptr, ldX), "pg_cast_f64_f32_dev")
                                         _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dXf.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
                                 elif x8:         # 8-bit block (always finite): genotype codes or split planes, chosen on the device
-                                    _lib.check(L.pg_rotate_auto_i8_dev(ctx.handle, n, pb, dprep.ptr, dX.ptr, int(X.dtype == np.uint8), ldX,
+                                    _lib.check(L.pg_rotate_auto_i8_dev(ctx.handle, n, pb, dprep.ptr, dXc.ptr, int(X.dtype == np.uint8), ldX,
                                                                        dXr.ptr, ldx, dwork.ptr, None), "pg_rotate_auto_i8_dev")
                                 elif eigen:      # float32 block: path (genotype fp16x2 / split planes / fp32 MFMA) chosen on the device, no host wait
-                                    _lib.check(L.pg_rotate_auto_dev(ctx.handle, n, pb, dU.ptr, n, dprep.ptr, dX.ptr, ldX, dXr.ptr, ldx,
+                                    _lib.check(L.pg_rotate_auto_dev(ctx.handle, n, pb, dU.ptr, n, dprep.ptr, dXc.ptr, ldX, dXr.ptr, ldx,
                                                                     dwork.ptr, None), "pg_rotate_auto_dev")
                                 elif not snp_major:
-                                    _lib.check(L.pg_transpose_dev(ctx.handle, n, pb, dX.ptr, ldX, dXr.ptr, ldx), "pg_transpose_dev")
+                                    _lib.check(L.pg_transpose_dev(ctx.handle, n, pb, dXc.ptr, ldX, dXr.ptr, ldx), "pg_transpose_dev")
                                 # result block: [F | p | beta | se | tau | lambda] (+ [l_alt | l_null | D_lrt | p_lrt] f64 with lrt)
                                 r0 = dres.ptr
                                 if lrt:
@@ -275,6 +347,9 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                 _lib.check(L.pg_memcpy_d2h_async(ctx.handle, stg.out, r0, pb * nout), "pg_memcpy_d2h_async")
                                 ctx.sync()
                                 t_ker = time.time()
+                            if pbuf is not None and stats is not None:      # (the buffer is freed with the prefetcher: hipFree would drain the device here)
+                                with lock:
+                                    stats["prefetched_batches"] = stats.get("prefetched_batches", 0) + 1
                             hb = np.frombuffer(hres, np.uint8, pb * nout)
                             FP = hb[:16 * pb].view(np.float64).reshape(2, pb)
                             res = hb[16 * pb:32 * pb].view(np.float32).reshape(4, pb)
@@ -423,6 +498,15 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
 
     t0 = time.time()
     ectx = dU0 = None  # the eigensolver's context on GPU 0 and U resident there (reused by GPU 0's SNP loop)
+    xpin = pre = None
+    if eigen and eigenpairs is None and not packed and not checkpoint and X.flags.c_contiguous and _PREFETCH_MAX > 0:
+        # the eigensolver leaves PCIe idle for ~0.6 s at n = 10 000 (52 s at 50 000): X starts moving now
+        try:
+            if not _lib.is_pinned(X):
+                xpin = _lib.pin(X)
+            pre = _Prefetch(L, X, blocks, n, X.dtype.itemsize, verbose)
+        except _lib.PgError as ex:
+            _log(verbose, f"X could not be page-locked in place ({ex}); no prefetch")
     if eigen:
         ectx = _lib.Context(0)
         try:
@@ -487,6 +571,10 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
             Yr, Wr = YW[:, :1], np.ascontiguousarray(YW[:, 1:])
             _log(verbose, f"Left multiplied Y, W by U.T - {time.time() - t1:.3f} s")
         except BaseException:
+            if pre is not None:
+                pre.close()
+            if xpin is not None:
+                xpin.close()
             ectx.close()
             raise
     else:
@@ -499,6 +587,10 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
         # lmm.py:253-256 (the reference tests the rotated arrays; a NaN anywhere in a raw column makes that
         # whole rotated column NaN, so testing the inputs raises in exactly the same cases)
         if (not packed and X.dtype.kind == 'f' and np.isnan(X).any()) or np.isnan(Yr).any() or np.isnan(Wr).any():
+            if pre is not None:
+                pre.close()
+            if xpin is not None:
+                xpin.close()
             if ectx is not None:
                 ectx.close()
             raise ValueError("NaNs present in data")
@@ -532,8 +624,11 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
                 json.dump(key, f)
     t2 = time.time()
     comms = None
-    xpin = None
     try:
+        if pre is not None:
+            pre.join()
+            if stats is not None:
+                stats["prefetched_bytes"] = int(pre.bytes)
         if not packed and not _lib.is_pinned(X):
             # page-lock the caller's X in place for the duration of the scan (hipHostRegister: ~5 ms/GB measured, tools/bench_h2d.py)
             # so that every batch is one 2-D DMA straight out of it; if the range cannot be registered (e.g. a read-only file
@@ -553,7 +648,7 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
         for dev_id, (a, b) in enumerate(blocks):
             th = threading.Thread(target=_run_block, args=(dev_id, a, b, n, c, eigenVals, Wr, yr1, X,
                                                            dUs[dev_id], comms[dev_id] if comms else None,
-                                                           grid, eigen, lrt, out, errs, verbose, checkpoint, stats))
+                                                           grid, eigen, lrt, out, errs, verbose, checkpoint, stats, pre))
             th.start()
             threads.append(th)
         for th in threads:
@@ -561,6 +656,8 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
         if stats is not None:
             stats["blocks_s"] = time.time() - t2          # page-locking + every GPU's block; what follows is teardown (frees)
     finally:
+        if pre is not None:
+            pre.close()
         if xpin is not None:
             xpin.close()
         if comms:

@@ -229,3 +229,23 @@ def test_fortran_ordered_snp_major_X_streams_without_a_host_transpose(eigen, how
     for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
         a, b = got[col].to_numpy(), ref[col].to_numpy()
         assert (a.view(np.uint8) == b.view(np.uint8)).all(), col
+
+
+def test_X_prefetched_during_the_eigendecomposition_same_bits(monkeypatch):
+    """eigen=True from K: batches of a page-lockable C-contiguous X are copied to the device while the eigensolver runs and the SNP
+    loop takes them from there; the rows are those of the run without prefetch, bit for bit, for float32 and int8 X."""
+    from pygemma_amd import lmm, synth
+    n, p, c = 1500, 6000, 3
+    raw = synth.panel(n, p, c, seed=33)
+    monkeypatch.setattr(lmm, "_BATCH_SNPS", 1024)
+    for X in (np.ascontiguousarray(raw["X"]), np.clip(np.round(raw["X"]), -3, 3).astype(np.int8)):
+        monkeypatch.setattr(lmm, "_PREFETCH_MAX", 0)
+        st0 = {}
+        ref = lmm.pygemma(raw["Y"], X, raw["W"], raw["K"], stats=st0)
+        assert "prefetched_batches" not in st0
+        monkeypatch.setattr(lmm, "_PREFETCH_MAX", 96 << 30)
+        st = {}
+        got = lmm.pygemma(raw["Y"], X, raw["W"], raw["K"], stats=st)
+        assert st.get("prefetched_batches", 0) >= 1 and st["prefetched_bytes"] > 0
+        for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
+            assert (got[col].to_numpy().view(np.uint8) == ref[col].to_numpy().view(np.uint8)).all(), col

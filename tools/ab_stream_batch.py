@@ -15,7 +15,8 @@ ref = None
 for tag, Xin in (("f32 pinned", Xp), ("int8 pageable", X8)):
     for bs in sizes + sizes[:1]:
         lmm._BATCH_SNPS = bs
-        lmm._WORKERS = int(os.environ.get('PG_AB_WORKERS', lmm._WORKERS)); lmm._BATCH_COUNT = int(os.environ.get('PG_AB_COUNT', lmm._BATCH_COUNT)); lmm._SERIAL_KERNELS = bool(int(os.environ.get('PG_AB_SERIAL', '1')))
+        lmm._WORKERS = int(os.environ.get('PG_AB_WORKERS', lmm._WORKERS)); lmm._BATCH_COUNT = int(os.environ.get('PG_AB_COUNT', lmm._BATCH_COUNT)); lmm._SERIAL_KERNELS = bool(int(os.environ.get('PG_AB_SERIAL', '0')))
+        if 'PG_AB_PREFETCH' in os.environ: lmm._PREFETCH_MAX = int(float(os.environ['PG_AB_PREFETCH']))
         st = {}
         t = time.time(); df = lmm.pygemma(y, Xin, W, K, stats=st); dt = time.time() - t
         if ref is None: ref = df
