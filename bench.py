@@ -418,10 +418,12 @@ def main():
             for tag, Xin in (("pinned_X", Xp), ("pageable_X", dX_host)):
                 st = {}
                 tt = time.perf_counter()
-                df = lmm.pygemma(Yh, Xin, Wh, Khost, stats=st)
+                df = lmm.pygemma(Yh, Xin, Wh, Khost, stats=st, verbose=int(os.environ.get("PYGEMMA_BENCH_VERBOSE", "0")))
                 dt = time.perf_counter() - tt
                 e2e[tag] = {"seconds": dt, "snps_per_s": P / dt, "snp_loop_seconds": st.get("seconds"), "snp_loop_snps_per_s": P / st["seconds"],
-                            "host_to_device_GBps_incl_compute": st["bytes_in"] / st["seconds"] / 1e9, "batches": st["batches"]}
+                            "host_to_device_GBps_incl_compute": st["bytes_in"] / st["seconds"] / 1e9, "batches": st["batches"],
+                            "prefetched_batches": st.get("prefetched_batches", 0),
+                            "stages_s": {k: round(float(st[k]), 4) for k in ("dma_s", "kernel_s", "blocks_s", "setup_s", "worker_alloc_s") if k in st}}
                 assert np.isfinite(df["beta"].to_numpy()).all()
             e2e["note"] = (f"lmm.pygemma(Y, X, W, K) from host float32 arrays, p={P}: K upload + eigh + rotation + scan + frame; snp_loop = the "
                            "streamed SNP loop alone (H2D DMA of X included). PCIe-inclusive, never `value`.")

@@ -47,7 +47,12 @@ _BATCH_MIN = 8192        # ... and at least, while the block is cut into up to _
 _BATCH_COUNT = 12        # last batch's kernels are the part of the loop that does not overlap (measured at p = 100 000: 4 batches
                          # 0.149-0.172 s, 8: 0.116, 12: 0.112, 16: 0.112 — tools/ab_stream_batch.py)
 _STAGE_THREADS = 8       # host copy threads per worker for the pageable -> pinned leg
-_PREFETCH_MAX = 96 << 30     # device bytes of X per GPU that may be copied in while the eigensolver runs
+# Device bytes of X per GPU that may be copied in while the eigensolver runs.  OFF by default (0): with the caller's X in
+# hipHostMalloc'ed memory (pinned_empty) it takes the copy time out of the loop (p = 400 000 float32: 0.96 -> 0.90 s end to end), but
+# inside a long-lived process the first allocations after the eigensolver were seen to stall for ~0.15 s in one run out of four, and
+# from memory page-locked in place (hipHostRegister) the run was 0.25 s SLOWER every time (tools/ab_stream_batch.py, bench.py e2e leg
+# with PYGEMMA_PREFETCH_MAX=1e11).  Opt-in: PYGEMMA_PREFETCH_MAX=<bytes>; only an X the caller pinned himself is prefetched.
+_PREFETCH_MAX = int(float(os.environ.get("PYGEMMA_PREFETCH_MAX", 0)))
 _PREFETCH_MARGIN = 8 << 30  # ... and what is left untouched beside the eigensolver's and the workers' buffers
 
 
@@ -65,9 +70,14 @@ class SampleIter:
                 yield a, b
 
 
+_T_LOG = [time.time()]
+
+
 def _log(verbose, msg):
     if verbose > 0:
-        print(f"[pygemma_amd] {msg}", flush=True)
+        now = time.time()
+        print(f"[pygemma_amd +{now - _T_LOG[0]:7.3f} s] {msg}", flush=True)
+        _T_LOG[0] = now
 
 
 def _rotate_small(ctx, L, n, dU, A):
@@ -139,47 +149,63 @@ def _batch_geometry(n, a, b):
     return pb_max, (pb_max + 15) // 16 * 16
 
 
+class _View:
+    """A range of a device buffer (what a worker needs of a batch: its address)."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+
 class _Prefetch:
     """X on its way to the devices WHILE the eigensolver runs (eigen=True from K; X a C-contiguous, page-locked host matrix): one
-    host thread per GPU DMAs the leading batches of that GPU's block into device buffers on a stream of its own — PCIe and the
-    HBM-bound tridiagonalisation do not compete — within what hipMemGetInfo leaves after the eigensolver's workspace (~60 n^2
-    bytes on GPU 0) and the workers' own buffers.  The SNP loop then takes those buffers instead of issuing the copies: at
-    p = 100 000 the loop drops from 0.11 to the kernels' 0.07 s, at 288 GB of HBM a 40 GB float32 X is resident before U is."""
+    host thread per GPU DMAs the leading batches of that GPU's block into ONE device buffer (allocated here, before the eigensolver
+    starts: no allocation competes with its launches) on a stream of its own — PCIe and the HBM-bound tridiagonalisation do not
+    compete — within what hipMemGetInfo leaves after the eigensolver's workspace (~60 n^2 bytes on GPU 0) and the workers' own
+    buffers.  The SNP loop then takes those batches instead of issuing the copies: the loop runs at the kernels' rate, and at
+    288 GB of HBM a 40 GB float32 X is resident before U is."""
 
     def __init__(self, L, X, blocks, n, esz, verbose):
         self.L, self.X, self.n, self.esz, self.verbose = L, X, n, esz, verbose
         self.lock = threading.Lock()
-        self.bufs = [dict() for _ in blocks]
-        self.ctxs = [None] * len(blocks)
+        self.ready = [dict() for _ in blocks]
+        self.ctxs, self.plans = [], []
         self.bytes = 0
         self.stop = False                        # set when the eigensolver is done: the batch in flight is the last one
-        self.threads = [threading.Thread(target=self._run, args=(g, a, b)) for g, (a, b) in enumerate(blocks)]
-        for th in self.threads:
-            th.start()
-
-    def _run(self, g, a, b):
-        try:
-            n, esz, p = self.n, self.esz, self.X.shape[1]
-            ctx = self.ctxs[g] = _lib.Context(g)
+        for g, (a, b) in enumerate(blocks):
+            ctx = _lib.Context(g)
+            self.ctxs.append(ctx)
             free, _total = ctx.mem_info()
             reserve = (72 * n * n if g == 0 else 12 * n * n) + 2 * _BATCH_BYTES + _PREFETCH_MARGIN
             budget = min(free - reserve, _PREFETCH_MAX)
             pb_max, ldX = _batch_geometry(n, a, b)
-            used = 0
-            for s in range(a, b, pb_max):
-                e = min(s + pb_max, b)
-                nbytes = n * ldX * esz
-                if used + nbytes > budget or self.stop:
+            per = n * ldX * esz
+            batches = [(s, min(s + pb_max, b)) for s in range(a, b, pb_max)]
+            batches = batches[: max(0, int(budget // per))]
+            big = ctx.alloc(per * len(batches)) if batches else None
+            self.plans.append((batches, big, per, ldX))
+        self.threads = [threading.Thread(target=self._run, args=(g,)) for g in range(len(blocks))]
+        for th in self.threads:
+            th.start()
+
+    def _run(self, g):
+        try:
+            n, esz, p = self.n, self.esz, self.X.shape[1]
+            ctx = self.ctxs[g]
+            batches, big, per, ldX = self.plans[g]
+            done = 0
+            for k, (s, e) in enumerate(batches):
+                if self.stop:
                     break
-                buf = ctx.alloc(nbytes)
-                _lib.check(self.L.pg_memcpy2d_h2d_async(ctx.handle, buf.ptr, ldX * esz, self.X.ctypes.data + esz * s, p * esz, (e - s) * esz, n),
+                dst = big.ptr + k * per
+                _lib.check(self.L.pg_memcpy2d_h2d_async(ctx.handle, dst, ldX * esz, self.X.ctypes.data + esz * s, p * esz, (e - s) * esz, n),
                            "pg_memcpy2d_h2d_async")
                 ctx.sync()                       # a batch is offered only once it has landed
                 with self.lock:
-                    self.bufs[g][(s, e)] = buf
+                    self.ready[g][(s, e)] = _View(dst)
                     self.bytes += n * (e - s) * esz
-                used += nbytes
-            _log(self.verbose, f"GPU {g}: {used / 1e9:.2f} GB of X prefetched during the eigendecomposition")
+                done += n * (e - s) * esz
+                _log(self.verbose - 1, f"GPU {g}: SNPs [{s},{e}) prefetched")
+            _log(self.verbose, f"GPU {g}: {done / 1e9:.2f} GB of X prefetched during the eigendecomposition")
         except Exception as ex:                  # prefetching is an optimisation: on any failure the loop copies as usual
             _log(self.verbose, f"GPU {g}: prefetch stopped ({ex!r})")
 
@@ -190,14 +216,13 @@ class _Prefetch:
 
     def take(self, g, s, e):
         with self.lock:
-            return self.bufs[g].pop((s, e), None)
+            return self.ready[g].pop((s, e), None)
 
     def close(self):
         self.join()
-        for g, ctx in enumerate(self.ctxs):
-            if ctx is not None:
-                ctx.close()                      # frees what was not taken
-        self.ctxs = [None] * len(self.ctxs)
+        for ctx in self.ctxs:
+            ctx.close()                          # frees the buffers (after the loop: hipFree inside it would drain the device)
+        self.ctxs = []
 
 
 def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out, errs, verbose, ckpt=None, stats=None, pre=None):
@@ -502,11 +527,10 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     if eigen and eigenpairs is None and not packed and not checkpoint and X.flags.c_contiguous and _PREFETCH_MAX > 0:
         # the eigensolver leaves PCIe idle for ~0.6 s at n = 10 000 (52 s at 50 000): X starts moving now
         try:
-            if not _lib.is_pinned(X):
-                xpin = _lib.pin(X)
-            pre = _Prefetch(L, X, blocks, n, X.dtype.itemsize, verbose)
+            if _lib.is_pinned(X):
+                pre = _Prefetch(L, X, blocks, n, X.dtype.itemsize, verbose)
         except _lib.PgError as ex:
-            _log(verbose, f"X could not be page-locked in place ({ex}); no prefetch")
+            _log(verbose, f"prefetch not started ({ex})")
     if eigen:
         ectx = _lib.Context(0)
         try:

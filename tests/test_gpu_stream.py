@@ -232,13 +232,15 @@ def test_fortran_ordered_snp_major_X_streams_without_a_host_transpose(eigen, how
 
 
 def test_X_prefetched_during_the_eigendecomposition_same_bits(monkeypatch):
-    """eigen=True from K: batches of a page-lockable C-contiguous X are copied to the device while the eigensolver runs and the SNP
-    loop takes them from there; the rows are those of the run without prefetch, bit for bit, for float32 and int8 X."""
+    """Opt-in (PYGEMMA_PREFETCH_MAX): with eigen=True from K, batches of a pinned C-contiguous X are copied to the device while the
+    eigensolver runs and the SNP loop takes them from there; the rows are those of the run without prefetch, bit for bit."""
     from pygemma_amd import lmm, synth
     n, p, c = 1500, 6000, 3
     raw = synth.panel(n, p, c, seed=33)
     monkeypatch.setattr(lmm, "_BATCH_SNPS", 1024)
-    for X in (np.ascontiguousarray(raw["X"]), np.clip(np.round(raw["X"]), -3, 3).astype(np.int8)):
+    Xf = lmm.pinned_empty((n, p), np.float32); Xf[:] = raw["X"]
+    X8 = lmm.pinned_empty((n, p), np.int8); X8[:] = np.clip(np.round(raw["X"]), -3, 3)
+    for X in (Xf, X8):          # the opt-in prefetch takes only an X the caller pinned himself
         monkeypatch.setattr(lmm, "_PREFETCH_MAX", 0)
         st0 = {}
         ref = lmm.pygemma(raw["Y"], X, raw["W"], raw["K"], stats=st0)
