@@ -251,3 +251,14 @@ def test_X_prefetched_during_the_eigendecomposition_same_bits(monkeypatch):
         assert st.get("prefetched_batches", 0) >= 1 and st["prefetched_bytes"] > 0
         for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
             assert (got[col].to_numpy().view(np.uint8) == ref[col].to_numpy().view(np.uint8)).all(), col
+
+
+def test_mem_info_reports_the_device():
+    from pygemma_amd import _lib
+    with _lib.Context(0) as ctx:
+        free0, total = ctx.mem_info()
+        assert 0 < free0 <= total and total > (64 << 30)          # an MI355X has 288 GB
+        buf = ctx.alloc(1 << 30)
+        free1, _ = ctx.mem_info()
+        assert free0 - free1 >= (1 << 30) - (64 << 20)
+        buf.free()
