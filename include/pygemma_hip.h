@@ -241,7 +241,8 @@ int pg_syevd_dev(pg_ctx *ctx, int64_t n, const float *K, float *evals, float *U,
  *     P3/Q3/R3 : m*m*m float32 each, indexed [row][level][col] like wjt_Pi_wk / wjt_Pi_Pi_wk / wjt_Pi_Pi_Pi_wk;
  *                entries the reference leaves undefined (np.empty) are NaN; R3 all NaN unless full.
  *     vecs     : [5][m] = yt_Pi_y, yt_Pi_Pi_y, yt_Pi_Pi_Pi_y, tr_Pi, tr_Pi_Pi per level.
- *     scal     : 8 floats = logdet_Wt_H_inv_W, logdet_H, then d1, d2 (NaN unless full), logL at the last level.
+ *     scal     : 8 floats = logdet_Wt_H_inv_W, logdet_H, then d1, d2 (NaN unless full), logL at the last level, sum h, sum h^2
+ *                (NaN unless full): the un-projected traces the ML functions use.
  * pg_newton_dev         : newton(lam, eigenVals, Y, W, precompute=True, lambda_min, lambda_max) (pyx:1349-1416) -> *root.
  * pg_reml_scalars_dev   : args8 = {lam, yPy, yPPy, yPPPy, trP, trPP, logdet_H, logdet_Wt_H_inv_W} ->
  *     out3 = {likelihood_restricted_lambda_overload (pyx:1813), likelihood_derivative1_..._overload (pyx:1656),
@@ -251,6 +252,9 @@ int pg_precompute_mat_dev(pg_ctx *ctx, int64_t n, int ctot, float lam, const flo
 int pg_newton_dev(pg_ctx *ctx, int64_t n, int ctot, float lam, float lam_min, float lam_max, const float *d,
                   const float *Wx, const float *y, float *root);
 int pg_reml_scalars_dev(pg_ctx *ctx, int64_t n, int ctot, const float *args8, float *out3);
+/* pg_ml_scalars_dev     : args7 = {lam, yPy, yPPy, yPPPy, sum h, sum h^2, logdet_H} -> out3 = {likelihood_lambda (pyx:1542),
+ *     likelihood_derivative1_lambda (pyx:1567), likelihood_derivative2_lambda (pyx:1586)}: the ML scalars of the LRT (N2). */
+int pg_ml_scalars_dev(pg_ctx *ctx, int64_t n, const float *args7, float *out3);
 
 /* ---- Test hooks of the eigensolver's stages (tests/test_gpu_syevd.py, tools/bench_dgemm.py): not part of the drop-in
  * surface, exported so that each stage can be checked against host LAPACK on its own.

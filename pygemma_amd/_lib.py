@@ -17,7 +17,7 @@ SYMBOLS = [
     "pg_ctx_destroy", "pg_ctx_sync", "pg_ctx_device", "pg_mem_info", "pg_malloc", "pg_free", "pg_memcpy_h2d", "pg_memcpy_d2h",
     "pg_memset", "pg_memcpy2d_h2d", "pg_event_create", "pg_event_destroy", "pg_event_record", "pg_event_elapsed_ms",
     "pg_kinship_dev", "pg_geno_prep_bytes", "pg_geno_work_bytes", "pg_geno_prep_dev", "pg_rotate_geno_dev", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev", "pg_transpose_dev", "pg_rotate_dev", "pg_syevd_dev",
-    "pg_precompute_mat_dev", "pg_newton_dev", "pg_reml_scalars_dev", "pg_rotate_bed_dev", "pg_rotate_geno_i8_dev", "pg_cast_i8_f32_dev", "pg_assoc_multi", "pg_rotate_geno_f64_dev", "pg_cast_f64_f32_dev",
+    "pg_precompute_mat_dev", "pg_newton_dev", "pg_reml_scalars_dev", "pg_ml_scalars_dev", "pg_rotate_bed_dev", "pg_rotate_geno_i8_dev", "pg_cast_i8_f32_dev", "pg_assoc_multi", "pg_rotate_geno_f64_dev", "pg_cast_f64_f32_dev",
     "pg_host_alloc", "pg_host_free", "pg_host_register", "pg_host_unregister", "pg_memcpy_h2d_async", "pg_memcpy_d2h_async",
     "pg_memcpy_d2d_async", "pg_memcpy2d_h2d_async", "pg_stage_rows", "pg_event_sync", "pg_stream_wait_event",
     "pg_comm_unique_id", "pg_comm_init_rank", "pg_comm_init_all", "pg_comm_destroy", "pg_comm_size", "pg_comm_rank",
@@ -101,6 +101,8 @@ def load():
     L.pg_precompute_mat_dev.argtypes = [vp, i64, i32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.pg_newton_dev.argtypes = [vp, i64, i32, f32, f32, f32, vp, vp, vp, vp]
     L.pg_reml_scalars_dev.argtypes = [vp, i64, i32, vp, vp]
+    L.pg_ml_scalars_dev.argtypes = [vp, i64, vp, vp]
+    L.pg_ml_scalars_dev.restype = i32
     L.pg_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     L.pg_host_free.argtypes = [vp, vp]
     L.pg_host_register.argtypes = [vp, vp, sz]

@@ -1243,6 +1243,8 @@ __global__ __launch_bounds__(64) void precompute_kernel(InspectParams ip)
         ip.scal[2] = d1_f(ip.pr, ip.lam, eo.yPy, eo.yPPy, eo.trP);
         ip.scal[3] = ip.full ? d2_f(ip.pr, ip.lam, eo.yPy, eo.yPPy, eo.yPPPy, eo.trP, eo.trPP) : NAN;
         ip.scal[4] = logl_f(ip.pr, eo.yPy, ldH, eo.ld);
+        ip.scal[5] = (float)tr[0];                          // sum h   (un-projected trace of H^-1: the ML functions, pyx:1567-1603)
+        ip.scal[6] = ip.full ? (float)tr[1] : NAN;          // sum h^2
     }
 }
 
@@ -1505,6 +1507,31 @@ extern "C" int pg_reml_scalars_dev(pg_ctx *ctx, int64_t n, int ctot, const float
         pr.logl_c = r;
     }
     reml_scalars_kernel<<<1, 1, 0, ctx->stream>>>(pr, args8, out3);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+// N2 at the model level: likelihood_lambda (pyx:1542-1562), likelihood_derivative1_lambda (pyx:1567-1581),
+// likelihood_derivative2_lambda (pyx:1586-1603) from the quadratic forms of precompute_mat — the statements the LRT kernel runs
+__global__ void ml_scalars_kernel(AssocParams pr, const float *a, float *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    out[0] = ml_logl_f(pr, a[1], a[6]);
+    out[1] = ml_d1_f(pr, a[0], a[1], a[2], a[4]);
+    out[2] = ml_d2_f(pr, a[0], a[1], a[2], a[3], a[4], a[5]);
+}
+extern "C" int pg_ml_scalars_dev(pg_ctx *ctx, int64_t n, const float *args7, float *out3)
+{
+    PG_REQUIRE(ctx && args7 && out3 && n >= 2 && n < (1LL << 30), "pg_ml_scalars_dev: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    AssocParams pr{};
+    pr.n = (int)n;
+    pr.nhalf = (int)(n / 2);                                                     // (n/2): C integer division
+    {
+        float r = (float)((double)(n / 2) * std::log((double)n / (2.0 * M_PI)));  // pyx:1552
+        pr.ml_c = r - (float)(n / 2);                                             // pyx:1554
+    }
+    ml_scalars_kernel<<<1, 1, 0, ctx->stream>>>(pr, args7, out3);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }

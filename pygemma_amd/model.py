@@ -19,7 +19,8 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["precompute_mat", "calc_lambda_restricted", "calc_beta_vg_ve_restricted_overload", "newton",
+__all__ = ["precompute_mat", "calc_lambda_restricted", "calc_beta_vg_ve_restricted_overload", "newton", "calc_lambda",
+           "likelihood_lambda", "likelihood_derivative1_lambda", "likelihood_derivative2_lambda",
            "likelihood_restricted_lambda_overload", "likelihood_derivative1_restricted_lambda_overload",
            "likelihood_derivative2_restricted_lambda_overload", "wrapper_likelihood_derivative1_restricted_lambda"]
 
@@ -61,6 +62,7 @@ def precompute_mat(lam, eigenVals, W, Y, full=False, ctx=None):
     if full:
         out.update({"wjt_Pi_Pi_Pi_wk": R3[:ctot, :, :ctot], "tr_Pi_Pi": vecs[4], "yt_Pi_Pi_Pi_y": vecs[2]})
     out["_d1"], out["_d2"], out["_logl"] = scal[2], scal[3], scal[4]   # the three scalars at the last level (extra)
+    out["_sum_h"], out["_sum_h2"] = scal[5], scal[6]                    # un-projected traces sum h, sum h^2 (the ML functions)
     return out
 
 
@@ -152,3 +154,72 @@ def calc_beta_vg_ve_restricted_overload(eigenVals, W, x, lam, Y, ctx=None):
                              (np.float64(np.sqrt(max(P[c, c, c], MIN_VAL))) * np.sqrt(np.float64(n - c - 1))))
         tau = np.float32(np.float32(n - c - 1) / ytPxy)
     return np.float32(beta), 0.0, np.float32(se_beta), np.float32(tau)
+
+
+# ---- N2 at the model level: the ML functions the reference's calc_lambda is made of (lmm/lmm.py:22-84; pyx:1542-1603) ----------------
+def _ml_scalars(lam, eigenVals, Y, W, full, ctx=None):
+    """(likelihood_lambda, likelihood_derivative1_lambda, likelihood_derivative2_lambda) at `lam` for the model Y ~ W (every column
+    of W projected out, the SNP — if there is one — being its last column): the quadratic forms come from precompute_mat's sweeps on
+    the device, the scalars from pg_ml_scalars_dev (the statements the LRT kernel runs).  d2 is NaN unless full."""
+    L = _lib.load()
+    Wx = _f32(W)
+    n, ctot = Wx.shape
+    ctx, own = _ctx(ctx)
+    try:
+        r = precompute_mat(lam, eigenVals, Wx, Y, full=full, ctx=ctx)
+        yPy, yPPy = r["yt_Pi_y"][ctot], r["yt_Pi_Pi_y"][ctot]
+        yPPPy = r["yt_Pi_Pi_Pi_y"][ctot] if full else np.float32(0)
+        args = np.array([np.float32(lam), yPy, yPPy, yPPPy, r["_sum_h"], r["_sum_h2"] if full else 0.0, r["logdet_H"]], np.float32)
+        da, do = ctx.to_device(args), ctx.alloc(12)
+        _lib.check(L.pg_ml_scalars_dev(ctx.handle, n, da.ptr, do.ptr), "pg_ml_scalars_dev")
+        ctx.sync()
+        out = do.download((3,), np.float32)
+        da.free(); do.free()
+        if not full:
+            out[2] = np.nan
+        return out
+    finally:
+        if own:
+            ctx.close()
+
+
+def likelihood_lambda(lam, eigenVals, Y, W, ctx=None):
+    """pyx:1542: the ML log-likelihood at lam (np.float32)."""
+    return np.float32(_ml_scalars(lam, eigenVals, Y, W, False, ctx)[0])
+
+
+def likelihood_derivative1_lambda(lam, eigenVals, Y, W, ctx=None):
+    """pyx:1567."""
+    return np.float32(_ml_scalars(lam, eigenVals, Y, W, False, ctx)[1])
+
+
+def likelihood_derivative2_lambda(lam, eigenVals, Y, W, ctx=None):
+    """pyx:1586."""
+    return np.float32(_ml_scalars(lam, eigenVals, Y, W, True, ctx)[2])
+
+
+def calc_lambda(eigenVals, Y, W, ctx=None):
+    """lmm/lmm.py:22-84: the ML lambda of the model Y ~ W — per decade of [1e-5, 1e5] with a sign change of dlogL/dlambda one root by
+    scipy's brentq(rtol=0.1, maxiter=5000) refined by scipy's newton(fprime=d2, rtol=1e-5, maxiter=10), the two ends as further
+    candidates, the one with the largest likelihood_lambda returned.  Same SciPy calls as the reference, the functions evaluated on
+    the device.  (lmm.pygemma(..., lrt=True) runs this search inside the association kernel for every SNP at once.)"""
+    from scipy import optimize
+    ctx, own = _ctx(ctx)
+    try:
+        d1 = lambda l: likelihood_derivative1_lambda(l, eigenVals, Y, W, ctx)                    # noqa: E731
+        d2 = lambda l: likelihood_derivative2_lambda(l, eigenVals, Y, W, ctx)                    # noqa: E731
+        roots = [np.power(10.0, -5.0), np.power(10.0, 5.0)]
+        f1 = None
+        for k in np.arange(-5.0, 5.0, 1.0, dtype=np.float32):
+            lambda0, lambda1 = 10.0 ** k, 10.0 ** (k + 1.0)
+            f0 = d1(lambda0) if f1 is None else f1
+            f1 = d1(lambda1)
+            if np.sign(f0) * np.sign(f1) < 0:
+                root = optimize.brentq(f=d1, a=lambda0, b=lambda1, rtol=0.1, maxiter=5000, disp=False)
+                root = optimize.newton(func=d1, x0=root, rtol=1e-5, fprime=d2, maxiter=10, disp=False)
+                roots.append(root)
+        ll = [likelihood_lambda(lam, eigenVals, Y, W, ctx) for lam in roots]
+        return roots[int(np.argmax(ll))]
+    finally:
+        if own:
+            ctx.close()

@@ -145,3 +145,39 @@ def test_model_functions_on_reference_own_test_matrices(ctx):
         assert np.isfinite(got) == np.isfinite(ref) and abs(got - ref) <= 5e-2 * abs(ref) + 1e-12, (li, got, ref)
     assert lmm.calc_lambda_restricted(d, Y, Wx, ctx=ctx) == z["calc_lambda_restricted"]
     assert lmm.calc_lambda_restricted(d, Y, Wx, grid=True, ctx=ctx) == z["calc_lambda_restricted_grid"]
+
+
+def test_ml_functions_and_calc_lambda_vs_reference_fixtures():
+    """N2 at the model level: lmm.likelihood_lambda / likelihood_derivative1_lambda / likelihood_derivative2_lambda (pyx:1542-1603)
+    and lmm.calc_lambda (lmm/lmm.py:22-84) against what the real reference's functions returned (tests/golden/lrt_panels.npz), at the
+    tolerances of the oracle's own comparison (tests/test_oracle_golden.py): the reference forms these in float32."""
+    import os
+    from pygemma import lmm
+    from pygemma_amd import _lib
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "lrt_panels.npz"))
+    lams = z["lams"]
+    with _lib.Context(0) as ctx:
+        for name in ["sig", "c1"]:
+            d, Y, W, X = (z[f"{name}_{k}"] for k in "dYWX")
+            fn = z[f"{name}_ml_functions"]
+            for si, Wx in enumerate([W, np.c_[W, X[:, 0]]]):
+                Wx = np.ascontiguousarray(Wx, np.float32)
+                for li, lam in enumerate(lams):
+                    o = (lmm.likelihood_lambda(lam, d, Y, Wx, ctx=ctx), lmm.likelihood_derivative1_lambda(lam, d, Y, Wx, ctx=ctx),
+                         lmm.likelihood_derivative2_lambda(lam, d, Y, Wx, ctx=ctx))
+                    if lam <= 400:
+                        assert abs(o[0] - fn[si, li, 0]) <= 3 * np.spacing(np.float32(abs(fn[si, li, 0]))), (name, si, lam)
+                    elif lam <= 1e3:
+                        assert abs(o[0] / fn[si, li, 0] - 1) <= 2e-6, (name, si, lam)
+                    if 1e-3 < lam < 1e4:
+                        assert abs(o[1] / fn[si, li, 1] - 1) <= 1e-3 and abs(o[2] / fn[si, li, 2] - 1) <= 2e-3, (name, si, lam, o, fn[si, li])
+            # calc_lambda: the null model and the first SNPs of the alternative
+            ulp = np.spacing(np.float32(abs(float(z[f"{name}_l_null"]))))
+            lam0 = lmm.calc_lambda(d, Y, W, ctx=ctx)
+            assert abs(lam0 / float(z[f"{name}_lambda_null"]) - 1) <= 5e-5
+            assert abs(float(lmm.likelihood_lambda(np.float32(lam0), d, Y, W, ctx=ctx)) - float(z[f"{name}_l_null"])) <= 2 * ulp
+            for g in range(3):
+                Wx = np.ascontiguousarray(np.c_[W, X[:, g]], np.float32)
+                lam = lmm.calc_lambda(d, Y, Wx, ctx=ctx)
+                assert abs(lam / z[f"{name}_lambda_alt"][g] - 1) <= 5e-5, (name, g)
+                assert abs(float(lmm.likelihood_lambda(np.float32(lam), d, Y, Wx, ctx=ctx)) - float(z[f"{name}_l_alt"][g])) <= 2 * ulp
