@@ -95,7 +95,7 @@ def spawn_ranks(a):
     procs = []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   PYGEMMA_RDZV_KEY=f"bench{os.getpid()}")
+                   PYGEMMA_RDZV_KEY=f"bench{os.getpid()}_{os.urandom(8).hex()}")   # per-launch nonce
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     # wait for all; if one rank dies, the others would sit in the communicator's rendezvous for ever: end them (exact PIDs)
@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--null", type=int, default=0, help="1 = pure-noise phenotype (SURVEY 8d second phenotype) instead of the polygenic one")
     ap.add_argument("--weak", type=int, default=0, help="1 = weak-signal phenotype (h2 = 0.02): drives Newton towards its iteration cap")
     ap.add_argument("--fp32-rotate", type=int, default=0, help="1 = force the fp32-MFMA rotation even for genotype-valued X")
+    ap.add_argument("--raw-codes", type=int, default=0, help="1 = feed the raw 0/1/2 hard calls as float32 instead of the standardised columns SURVEY 8(d) specifies")
     ap.add_argument("--e2e", type=int, default=1, help="1 = after the timed region also run lmm.pygemma from host X (incl. H2D and eigh)")
     ap.add_argument("--eigh-cache", default="", help="npz path: reuse U, d (and K-derived inputs) from a previous run instead of running "
                                                      "the eigensolver (rocprofv3 --pmc passes on the per-SNP kernels)")
@@ -155,11 +156,6 @@ def main():
     L = _lib.load()
     if _lib.device_count() < 1:
         raise SystemExit("no GPU visible: the MI355X path has no CPU fallback")
-    if any(k in os.environ.get("LD_PRELOAD", "") for k in ("rocprofiler", "rocprof")) or "ROCPROFILER_REGISTER_FORCE_LOAD" in os.environ \
-            or any(k.startswith("ROCPROF") for k in os.environ):
-        # counter mode cannot track the ~3e4 un-synchronised dispatches of the tridiagonalisation (profiles/r02_pmc_abort_diagnosis.txt)
-        os.environ.setdefault("PG_SYEVD_PANEL_SYNC", "1")
-
     ctx = _lib.Context(local_rank)
     # PYGEMMA_BENCH_FORCE_COMM=1: form the (1-rank) communicator and run every collective on a single GPU too (rehearsal of the N > 1 path)
     comm = dist.init(ctx) if (world > 1 or os.environ.get("PYGEMMA_BENCH_FORCE_COMM")) else None
@@ -226,11 +222,23 @@ def main():
     # ---------------- this rank's genotype shard, resident in HBM as float32 (n x P) before any timed region
     t0 = time.time()
     X8 = geno_codes(np.random.default_rng(synth.SEED + 1000 + rank), n, P)
-    dX8 = ctx.to_device(X8)
+    dX8 = ctx.to_device(X8)     # stays: the int8-resident leg of the report rotates straight from it
     dX = ctx.alloc(n * P * 4)
-    _lib.check(L.pg_cast_i8_f32_dev(ctx.handle, n, P, dX8.ptr, 0, P, dX.ptr, P), "pg_cast_i8_f32_dev")   # reference layout (n, P) float32
-    ctx.sync()      # dX8 stays: the int8-resident leg of the report rotates straight from it
-    log(rank, f"genotype shard n={n} P={P} generated + resident: {time.time() - t0:.1f} s (host RNG)")
+    Xstd = None
+    if a.raw_codes:
+        _lib.check(L.pg_cast_i8_f32_dev(ctx.handle, n, P, dX8.ptr, 0, P, dX.ptr, P), "pg_cast_i8_f32_dev")   # reference layout (n, P) float32
+    else:
+        # hard calls standardised per SNP (what the reference's callers feed lmm.pygemma), float32, reference layout (n, P).
+        # Each column still holds <= 3 (almost) equally spaced values, so the device's own detection takes the same genotype path.
+        Xstd = np.empty((n, P), np.float32)
+        for s0 in range(0, P, 8192):
+            blk = X8[:, s0:s0 + 8192].astype(np.float32)
+            mu, sd = blk.mean(0, dtype=np.float64), blk.std(0, dtype=np.float64)
+            sd[sd == 0] = 1.0
+            Xstd[:, s0:s0 + 8192] = (blk - mu.astype(np.float32)) / sd.astype(np.float32)
+        dX.upload(Xstd)
+    ctx.sync()
+    log(rank, f"genotype shard n={n} P={P} ({'raw codes' if a.raw_codes else 'standardised'}) generated + resident: {time.time() - t0:.1f} s (host RNG)")
     batches = [(s, min(P, s + B)) for s in range(0, P, B)]
     dXr = ctx.alloc(B * ldx * 4)
     dprep = ctx.alloc(L.pg_geno_prep_bytes(n))
@@ -252,23 +260,25 @@ def main():
         ev_pool.append(e)
         return e
 
-    def step(events=None, fp32=False, int8=False):
-        for bi, (s, e) in enumerate(batches):
+    def step(events=None, fp32=False, int8=False, src=None, nsnp=None):
+        # src / nsnp: another resident float32 matrix (n, nsnp) in place of the shard (the dosage leg of the report)
+        xptr, ldsrc = (dX.ptr, P) if src is None else (src.ptr, nsnp)
+        for bi, (s, e) in enumerate(batches if src is None else [(s, min(nsnp, s + B)) for s in range(0, nsnp, B)]):
             pbn = e - s
             if events: L.pg_event_record(ctx.handle, events[bi][0])
             if int8:         # the same genotypes as the int8 matrix a caller may hand over (lmm.pygemma takes it as it is): 4x fewer bytes to scan
                 _lib.check(L.pg_rotate_auto_i8_dev(ctx.handle, n, pbn, dprep.ptr, dX8.ptr + s, 0, P, dXr.ptr, ldx, dwork.ptr, None),
                            "pg_rotate_auto_i8_dev")
             elif not fp32:   # path chosen on the device from the block's values (genotype codes -> fp16x2 MFMA); no host read-back
-                _lib.check(L.pg_rotate_auto_dev(ctx.handle, n, pbn, dU.ptr, n, dprep.ptr, dX.ptr + 4 * s, P, dXr.ptr, ldx, dwork.ptr,
+                _lib.check(L.pg_rotate_auto_dev(ctx.handle, n, pbn, dU.ptr, n, dprep.ptr, xptr + 4 * s, ldsrc, dXr.ptr, ldx, dwork.ptr,
                                                 dpath.ptr), "pg_rotate_auto_dev")
             else:
-                _lib.check(L.pg_rotate_dev(ctx.handle, n, pbn, dU.ptr, n, dX.ptr + 4 * s, P, dXr.ptr, ldx), "pg_rotate_dev")
+                _lib.check(L.pg_rotate_dev(ctx.handle, n, pbn, dU.ptr, n, xptr + 4 * s, ldsrc, dXr.ptr, ldx), "pg_rotate_dev")
             if events: L.pg_event_record(ctx.handle, events[bi][1])
             _lib.check(L.pg_assoc_dev(ctx.handle, n, c, pbn, dev.ptr, dW.ptr, dy.ptr, dXr.ptr, ldx, a.grid,
                                       pb + 4 * s, ps + 4 * s, pt + 4 * s, pl + 4 * s, pF + 8 * s, pP + 8 * s, dstats.ptr), "pg_assoc_dev")
             if events: L.pg_event_record(ctx.handle, events[bi][2])
-        if comm is not None:
+        if comm is not None and src is None:
             dist.gather_result_rows(comm, res.ptr, allres.ptr, P)      # RCCL over xGMI: 32 B per SNP, once per pass
 
     def barrier():
@@ -314,6 +324,18 @@ def main():
     t_int8 = None
     if comm is None:
         step(int8=True); ctx.sync(); tt = time.perf_counter(); step(int8=True); ctx.sync(); t_int8 = time.perf_counter() - tt
+    # dosage leg: finite X that is not genotype-valued (imputed dosages) takes the split-plane path (X itself in two fp16 planes)
+    t_dos, Pd, dos_path = None, min(P, 16384), None
+    if comm is None:
+        rd = np.random.default_rng(synth.SEED + 77)
+        Xd = np.clip(X8[:, :Pd].astype(np.float32) + rd.uniform(-0.3, 0.3, (n, Pd)).astype(np.float32), 0.0, 2.0)
+        dXd = ctx.to_device(np.ascontiguousarray(Xd))
+        step(src=dXd, nsnp=Pd); ctx.sync()
+        dos_path = int(dpath.download((1,), np.int32)[0])
+        tt = time.perf_counter(); step(src=dXd, nsnp=Pd); ctx.sync(); t_dos = time.perf_counter() - tt
+        dXd.free(); del Xd
+        step()                 # the shard's own rows back in `res` for the checks below
+        ctx.sync()
     # work-per-SNP tail: one more pass with the evaluation trace on
     dtrace = ctx.alloc(4 * B)
     tail = None
@@ -346,6 +368,8 @@ def main():
     # algorithmic fp64 flops of the assoc stage per SNP: decade scan 11 lambdas x 2 powers x m entries x 2n,
     # + per SNP-specific evaluation m(m+1)/2 entries x (2 | 3) powers x 2n
     assoc_flops_snp = 11 * 2 * m * 2.0 * n + (stats[0] * 2 + stats[1] * 3) * (m * (m + 1) / 2) * 2.0 * n
+    # SURVEY 8(d) row S-brent as written: (4 E_b + 6 E_n) n m with m = c + 2 entries per evaluation (E_b counts the 11 scan points too)
+    assoc_flops_snp_8d = (4.0 * (11 + stats[0]) + 6.0 * stats[1]) * n * m
     used_geno = (not a.fp32_rotate) and used_path == 1
     tr_rot, src_rot, shape_rot = pmc_traffic("rotate_geno_kernel" if used_geno else "rotate_kernel")
     tr_as, src_as, shape_as = pmc_traffic("assoc_kernel")
@@ -363,6 +387,11 @@ def main():
     rl_assoc = {"kernel": "assoc_kernel<%d> (+setup, p-values): fp64 VALU FMAs of the Gram passes, wave per SNP" % c, "bound": "valu",
                 "achieved": assoc_flops_snp * B / assoc_avg / 1e12, "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
                 "frac": assoc_flops_snp * B / assoc_avg / 1e12 / F64_VALU_PEAK_TF,
+                "flop_model": "this engine's own count, NOT SURVEY 8(d)'s: 11-point decade scan x 2 powers x m entries x 2n, plus per SNP-specific "
+                              "evaluation ALL m(m+1)/2 = %d Gram entries x (2|3) powers x 2n (lambda is per SNP, so the entries among W and y cannot be "
+                              "shared between SNPs); SURVEY 8(d) S-brent as written counts m = %d entries per evaluation: (4 E_b + 6 E_n) n m" % (m * (m + 1) // 2, m),
+                "flops_per_snp_survey_8d_literal": assoc_flops_snp_8d,
+                "frac_survey_8d_literal": assoc_flops_snp_8d * B / assoc_avg / 1e12 / F64_VALU_PEAK_TF,
                 "peak_note": "fp64 vector peak = fp64 matrix peak on MI355X (78.6 TF); only the Gram FMAs are counted (conversions, "
                              "h*w products, reciprocals, reductions and sweeps are not)",
                 "traffic": tr_as if same_shape else None, "traffic_source": src_as if same_shape else None,
@@ -375,7 +404,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": f"{rot_label} rotation + f64 Gram/sweeps (f32 rounding points of the reference)", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: synthetic n={n}, c={c}, p={P} SNPs per GPU per step in {len(batches)} HBM-resident batches of "
-                               f"<= {B}: rotate (U'X) + REML {'grid' if a.grid else 'decade-scan+Brent+Newton'} + Wald F + p on device"
+                               f"<= {B}; X = {'raw 0/1/2 hard calls' if a.raw_codes else 'hard calls standardised per SNP (SURVEY 8d)'}, float32 (n, p): rotate (U'X) + REML {'grid' if a.grid else 'decade-scan+Brent+Newton'} + Wald F + p on device"
                                + ("; one RCCL all-gather of the result rows per step" if comm is not None else ""),
                    "n": n, "c": c, "snps_per_gpu_per_step": P, "batch": B, "lambda_path": "grid" if a.grid else "brent",
                    "phenotype": "pure noise" if a.null else ("weak signal h2=0.02" if a.weak else "polygenic h2=0.5 + one causal SNP"),
@@ -406,11 +435,16 @@ def main():
         out["value_int8_X"] = {"value": P / t_int8, "unit": "SNPs/s", "ms_per_step": 1e3 * t_int8,
                                "note": "same pass with X resident as the int8 genotype matrix (a dtype lmm.pygemma accepts as it is, lmm/lmm.py:121-122 "
                                        "casts any dtype): detect/encode scan 1 byte per genotype; one untimed-by-the-metric pass"}
+    if t_dos is not None:
+        out["value_dosage_split"] = {"value": Pd / t_dos, "unit": "SNPs/s", "ms_per_step": 1e3 * t_dos, "snps": Pd, "rotation_path_code": dos_path,
+                                     "note": "same rotate + assoc pass on %d SNPs of non-genotype finite X (hard call + uniform(-0.3, 0.3), clipped to [0, 2]): "
+                                             "the device's detection sends the block to the split-plane rotation (X itself in two fp16 planes, 2 passes); "
+                                             "one untimed-by-the-metric pass" % Pd}
     # ---------------- end to end through the public entry point, host inputs, H2D and eigh included (N = 1 only)
     if a.e2e and world == 1 and Khost is not None:
         try:
             from pygemma_amd import lmm
-            dX_host = dX.download((n, P), np.float32)
+            dX_host = Xstd if Xstd is not None else dX.download((n, P), np.float32)
             Xp = lmm.pinned_empty((n, P), np.float32)
             Xp[:] = dX_host
             Yh, Wh = np.ascontiguousarray(yW[:, :1]), np.ascontiguousarray(yW[:, 1:])     # the un-rotated inputs rank 0 started from

@@ -50,6 +50,14 @@ constexpr int WPB = 4;    // wavefronts (= SNPs) per workgroup
 #define PG_WAVES 2          // waves per SIMD the register allocation is held to
 #endif
 
+// Per-wave dynamic LDS of assoc_kernel — ONE definition for the kernel's carve-up and the host's launch size, so the two
+// cannot drift apart: [piv: 3 M doubles when the sweeps exchange their pivot column through LDS] | xent[NLAM][2M] doubles |
+// evs[NLAM] | d1s[NLAM] | lls[NLAM] | vals[n_vals], rounded up to 16 bytes.
+__host__ __device__ constexpr size_t assoc_per_wave_bytes(int M, bool sweep_lds, size_t evalout_bytes, int n_vals)
+{
+    return (((sweep_lds ? (size_t)3 * M * 8 : 0) + (size_t)NLAM * 2 * M * 8 + NLAM * evalout_bytes + 2 * NLAM * 4 + (size_t)n_vals * 4) + 15) & ~(size_t)15;
+}
+
 struct AssocParams {
     int n, npad, c, niter, nu, grid, rowf;  // nu = n - (c+1); rowf = floats per fixed row (multiple of 4)
     long long p, ldx;
@@ -795,8 +803,7 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
     if (g >= pr.p) return;  // whole wavefront leaves; no workgroup barrier is used anywhere in this kernel
     // per-wave LDS: xent[NLAM][2M] doubles | evs[NLAM] | d1s[NLAM] | lls[NLAM] | vals[n_vals]
     constexpr size_t piv_bytes = Shape<C>::SWEEP_LDS ? (size_t)3 * M * 8 : 0;
-    const size_t per_wave = piv_bytes + (size_t)NLAM * 2 * M * 8 + NLAM * sizeof(EvalOut) + 2 * NLAM * 4 + (size_t)pr.n_vals * 4;
-    unsigned char *base = smem + (size_t)wave * ((per_wave + 15) & ~(size_t)15);
+    unsigned char *base = smem + (size_t)wave * assoc_per_wave_bytes(M, Shape<C>::SWEEP_LDS, sizeof(EvalOut), pr.n_vals);
     double *piv = reinterpret_cast<double *>(base);          // pivot column exchange of the sweeps (c >= 14 only)
     base += piv_bytes;
     double *xent = reinterpret_cast<double *>(base);
@@ -934,21 +941,16 @@ __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams p
 
 // ------------------------------------------------------------------------------------------------
 // host side
-static size_t assoc_lds_bytes(int c, int n_vals)
-{
-    const int M = c + 2;
-    const int NP = M * (M + 1) / 2;
-    size_t per_wave = ((NP + 63) / 64 >= PG_SWEEP_LDS_MIN_SLOTS ? (size_t)3 * M * 8 : 0) + (size_t)NLAM * 2 * M * 8 + NLAM * sizeof(EvalOut) + 2 * NLAM * 4 + (size_t)n_vals * 4;
-    per_wave = (per_wave + 15) & ~(size_t)15;
-    return per_wave * WPB;
-}
-
 template <int C, bool LRT = false>
 static int launch_assoc(pg_ctx *ctx, AssocParams &pr)
 {
+    // launch size from the instantiation's own Shape (the same constexpr the kernel indexes with), checked on the host
+    // against the device limit before anything is launched
+    const size_t lds = (size_t)WPB * assoc_per_wave_bytes(Shape<C>::M, Shape<C>::SWEEP_LDS, sizeof(EvalOut), pr.n_vals);
+    static_assert(Shape<C>::M == C + 2, "Shape<C>::M");
+    PG_REQUIRE(pr.n_vals >= 0 && lds <= 160 * 1024, "assoc: c = %d, n_vals = %d need %zu bytes of LDS per workgroup", C, pr.n_vals, lds);
     setup_tabs_kernel<C><<<NLAM, 64, (size_t)pr.n_vals * 4 + 16, ctx->stream>>>(pr);
     PG_HIP(hipGetLastError());
-    const size_t lds = assoc_lds_bytes(C, pr.n_vals);
     if (lds > 64 * 1024)
         PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&assoc_kernel<C, LRT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long long nblk = (pr.p + WPB - 1) / WPB;

@@ -17,25 +17,26 @@
 
 namespace pg {
 
-// the part of rccl.h this file needs (ABI of librccl.so.1; values checked against /opt/rocm/include/rccl/rccl.h)
-typedef struct ncclComm *ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-enum { ncclSuccess = 0 };
-enum { ncclSum = 0, ncclMax = 2 };
-enum { ncclUint8 = 1, ncclFloat64 = 8 };
+// Types, enum values and prototypes come from the installed header itself (nothing hand-declared: a librccl whose ABI moved
+// fails here at build time, not at run time).  Only declarations are used: every entry point is resolved with dlsym, so the
+// library is not a link-time dependency.
+}  // namespace pg
+#include <rccl/rccl.h>
+namespace pg {
+static_assert(sizeof(ncclUniqueId) == 128, "pg_comm_unique_id / pg_comm_init_rank hand a 128-byte id across the C ABI");
 
 struct Rccl {
     void *handle = nullptr;
-    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-    int (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
 };
 static Rccl g_rccl;
 static std::mutex g_rccl_mu;
@@ -69,7 +70,7 @@ static int rccl_load()
 
 #define PG_NCCL(call)                                                                                   \
     do {                                                                                                \
-        int _r = (call);                                                                                \
+        ncclResult_t _r = (call);                                                                             \
         if (_r != ncclSuccess) {                                                                        \
             pg::set_error("%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
             return PG_EHIP;                                                                             \
@@ -118,7 +119,7 @@ extern "C" int pg_comm_init_rank(pg_ctx *ctx, int nranks, int rank, const void *
     pg_comm *c = new (std::nothrow) pg_comm();
     if (!c) { set_error("pg_comm_init_rank: out of host memory"); return PG_ENOMEM; }
     c->ctx = ctx; c->nranks = nranks; c->rank = rank;
-    int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
     if (r != ncclSuccess) { set_error("ncclCommInitRank(%d of %d) failed: %s", rank, nranks, g_rccl.GetErrorString(r)); delete c; return PG_EHIP; }
     rc = comm_finish(c);
     if (rc) { g_rccl.CommDestroy(c->comm); delete c; return rc; }
@@ -136,14 +137,26 @@ extern "C" int pg_comm_init_all(int ndev, pg_ctx *const *ctxs, pg_comm **out)
     std::vector<ncclComm_t> comms(ndev, nullptr);
     for (int g = 0; g < ndev; g++) devs[g] = ctxs[g]->device;
     PG_NCCL(g_rccl.CommInitAll(comms.data(), ndev, devs.data()));
+    // every RCCL handle gets its owner before any step that can fail: on a failure the whole set is destroyed here and
+    // the caller receives no handles (the communicators behind a failing index used to leak)
+    std::vector<pg_comm *> made(ndev, nullptr);
+    bool oom = false;
     for (int g = 0; g < ndev; g++) {
-        pg_comm *c = new (std::nothrow) pg_comm();
-        if (!c) { set_error("pg_comm_init_all: out of host memory"); return PG_ENOMEM; }
-        c->ctx = ctxs[g]; c->comm = comms[g]; c->nranks = ndev; c->rank = g;
-        rc = comm_finish(c);
-        out[g] = c;
-        if (rc) return rc;     // the caller destroys what was handed out
+        made[g] = new (std::nothrow) pg_comm();
+        if (!made[g]) { oom = true; continue; }
+        made[g]->ctx = ctxs[g]; made[g]->comm = comms[g]; made[g]->nranks = ndev; made[g]->rank = g;
     }
+    rc = PG_OK;
+    if (oom) { set_error("pg_comm_init_all: out of host memory"); rc = PG_ENOMEM; }
+    for (int g = 0; g < ndev && !rc; g++) rc = comm_finish(made[g]);
+    if (rc) {
+        for (int g = 0; g < ndev; g++) {
+            if (made[g]) { (void)pg_comm_destroy(made[g]); }
+            else if (comms[g]) { (void)g_rccl.CommDestroy(comms[g]); }
+        }
+        return rc;
+    }
+    for (int g = 0; g < ndev; g++) out[g] = made[g];
     return PG_OK;
 }
 

@@ -332,11 +332,13 @@ struct SytrdWork {
 static int sytrd_device(pg_ctx *ctx, int n, SytrdWork &w)
 {
     hipStream_t s = ctx->stream;
-    // PG_SYEVD_PANEL_SYNC=1: drain the stream after every panel.  rocprofv3's counter mode (--pmc) keeps per-dispatch state for
-    // every dispatch still in flight and runs off the end of it (SIGSEGV inside librocprofiler-sdk's hsa intercept, reached from
-    // the hipLaunchKernel of symv_sym_kernel) once ~10^4 launches are queued without a synchronisation, as this loop does at
-    // n = 10 000 (profiles/r02_pmc_abort_diagnosis.txt); with the queue kept short it profiles fine.  Costs ~2 ms per solve.
-    const bool panel_sync = getenv("PG_SYEVD_PANEL_SYNC") != nullptr;
+    // The stream is drained once per panel, always (~2 ms per solve at n = 10 000).  This loop queues ~3 launches per column;
+    // rocprofv3's counter mode (--pmc) keeps per-dispatch state for every dispatch still in flight and runs off the end of it
+    // (SIGSEGV inside librocprofiler-sdk's hsa intercept, reached from the hipLaunchKernel of symv_sym_kernel) once ~10^4 launches
+    // are queued without a synchronisation (profiles/r02_pmc_abort_diagnosis.txt).  The bound on the queue depth therefore
+    // lives here, for every caller, not in an opt-in knob; PG_SYEVD_PANEL_SYNC=0 turns it off for A/B timing.
+    const char *ps_env = getenv("PG_SYEVD_PANEL_SYNC");
+    const bool panel_sync = !(ps_env && ps_env[0] == '0' && ps_env[1] == '\0');
     for (int i0 = 0; i0 < n - 1; i0 += NB) {
         const int nbc = std::min(NB, n - 1 - i0);
         if (panel_sync) PG_HIP(hipStreamSynchronize(s));

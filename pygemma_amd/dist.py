@@ -8,7 +8,8 @@ the 32-byte per-SNP result rows in rank order = SNP order (the reference's order
     comm.close()
 
 Any launcher that sets those variables works (torch.distributed.run, srun, mpirun wrappers, bench.py's own spawner).
-The torch.distributed helpers at the bottom serve the CPU (gloo) tests of the sharding + row packing logic only.
+Nothing here imports torch: the world-size-2 CPU test (tests/test_dist_gloo.py) moves the same 32-byte row blocks as bytes
+over gloo with a transport helper of its own.
 """
 import ctypes as C
 import os
@@ -25,38 +26,68 @@ def shard_range(p, rank, world):
 
 
 # ---- rendezvous: the 128-byte RCCL id travels rank 0 -> others through a file on the node --------------------------------
+ID_BYTES = 128
+
+
+def _launch_epoch():
+    """Start time (Unix seconds) of the process all ranks of one launch share as parent, from /proc: an id file older than
+    that was left by an earlier launch that died between publishing and retiring it (same port, recycled pid)."""
+    try:
+        with open(f"/proc/{os.getppid()}/stat") as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])          # field 22: starttime, in clock ticks since boot
+        with open("/proc/stat") as f:
+            btime = next(int(line.split()[1]) for line in f if line.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, StopIteration, IndexError):
+        return 0.0
+
+
 def _rdzv_path():
-    d = os.environ.get("PYGEMMA_RDZV_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+    """<dir>/pygemma_rdzv_<uid>/<key>.id — a directory of this user's own (mode 0700).  The key is the launcher's nonce
+    (PYGEMMA_RDZV_KEY: bench.py's spawner draws a fresh one per launch) or, under launchers that give none, the port, the elastic run
+    id / restart count and the shared parent's pid."""
+    base = os.environ.get("PYGEMMA_RDZV_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+    d = os.path.join(base, f"pygemma_rdzv_{os.getuid()}")
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.lstat(d)
+    if not os.path.isdir(d) or os.path.islink(d) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError(f"rendezvous directory {d} is not a private directory of this user")
     key = "_".join(str(x) for x in (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
                                     os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"),
                                     os.environ.get("PYGEMMA_RDZV_KEY") or os.getppid()))     # ranks of one launch share a parent
-    return os.path.join(d, f"pygemma_rdzv_{key}.id")
+    return os.path.join(d, f"{key}.id")
 
 
 def exchange_id(rank, world, make_id, timeout=300.0, path=None):
-    """Rank 0 calls make_id() -> bytes and publishes it (write + atomic rename); the other ranks wait for the file.
-    Returns the id on every rank.  Single node by construction (the path's job is one node's GPUs)."""
+    """Rank 0 calls make_id() -> bytes and publishes it (exclusive create, mode 0600, atomic rename); the other ranks wait for a
+    file of exactly ID_BYTES bytes, owned by this user and not older than the launch.  Returns the id on every rank.
+    Single node by construction (the path's job is one node's GPUs)."""
     if world == 1:
         return make_id()
     path = path or _rdzv_path()
     if rank == 0:
         uid = make_id()
+        if len(uid) != ID_BYTES:
+            raise ValueError(f"RCCL id of {len(uid)} bytes (expected {ID_BYTES})")
         tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(uid)
-        os.replace(tmp, path)
+        os.replace(tmp, path)          # replaces a stale file of the same key, if any
         return uid
-    t0 = time.time()
+    t0, epoch = time.time(), _launch_epoch()
     while True:
         try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if uid:
+            fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+            with os.fdopen(fd, "rb") as f:
+                st = os.fstat(f.fileno())
+                uid = f.read(ID_BYTES + 1)
+            if len(uid) == ID_BYTES and st.st_uid == os.getuid() and st.st_mtime >= epoch - 1.0:
                 return uid
         except FileNotFoundError:
             pass
         if time.time() - t0 > timeout:
-            raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout:.0f} s (is rank 0 running?)")
+            raise TimeoutError(f"rank {rank}: no fresh {ID_BYTES}-byte RCCL id at {path} after {timeout:.0f} s (is rank 0 running?)")
         time.sleep(0.01)
 
 
@@ -77,7 +108,9 @@ class Communicator:
         self._lib, self.L = _lib, _lib.load()
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
         h = C.c_void_p()
-        buf = (C.c_char * 128).from_buffer_copy(uid[:128].ljust(128, b"\0"))
+        if len(uid) != ID_BYTES:
+            raise ValueError(f"RCCL id of {len(uid)} bytes (expected {ID_BYTES})")
+        buf = (C.c_char * ID_BYTES).from_buffer_copy(uid)
         _lib.check(self.L.pg_comm_init_rank(ctx.handle, self.world, self.rank, buf, C.byref(h)), "pg_comm_init_rank")
         self.handle = h
         self._scalar = ctx.alloc(8)
@@ -141,40 +174,24 @@ def unpack_block(host_bytes, cols, count):
             "F_wald": F.copy(), "p_wald": pv.copy()}
 
 
-# ---- row packing over torch.distributed (gloo on CPU): the tests' stand-in transport for the same sharding logic -----------
-def pack_rows(res):
-    """dict of per-SNP columns -> (p_local, 8) float32 rows carrying the bits of
-    [beta, se, tau, lambda(f32), F_wald (f64 = 2 words), p_wald (f64 = 2 words)] = 32 B per SNP."""
-    p = len(res["beta"])
-    rows = np.empty((p, 8), np.float32)
-    rows[:, 0], rows[:, 1], rows[:, 2] = res["beta"], res["se_beta"], res["tau"]
-    rows[:, 3] = np.asarray(res["lambda"], np.float64).astype(np.float32)
-    rows[:, 4:6] = np.ascontiguousarray(res["F_wald"], np.float64).view(np.float32).reshape(p, 2)
-    rows[:, 6:8] = np.ascontiguousarray(res["p_wald"], np.float64).view(np.float32).reshape(p, 2)
-    return rows
+def pack_block(res, cols):
+    """Inverse of unpack_block: the six columns of `count` <= cols SNPs -> the 32 * cols bytes of one rank's padded block
+    (what the device writes; used where a block is assembled on the host: tests, tools)."""
+    count = len(res["beta"])
+    b = np.zeros(32 * cols, np.uint8)
+    b[:8 * cols].view(np.float64)[:count] = res["F_wald"]
+    b[8 * cols:16 * cols].view(np.float64)[:count] = res["p_wald"]
+    f4 = b[16 * cols:32 * cols].view(np.float32).reshape(4, cols)
+    for k, name in enumerate(("beta", "se_beta", "tau", "lambda")):
+        f4[k, :count] = np.asarray(res[name]).astype(np.float32)
+    return b.tobytes()
 
 
-def unpack_rows(rows):
-    rows = np.ascontiguousarray(rows, np.float32)
-    return {"beta": rows[:, 0].copy(), "se_beta": rows[:, 1].copy(), "tau": rows[:, 2].copy(),
-            "lambda": rows[:, 3].astype(np.float64),
-            "F_wald": np.ascontiguousarray(rows[:, 4:6]).view(np.float64).reshape(-1),
-            "p_wald": np.ascontiguousarray(rows[:, 6:8]).view(np.float64).reshape(-1)}
-
-
-def gather_rows(rows_local, p, device=None):
-    """All ranks contribute their (p_local, 8) block; every rank gets the (p, 8) table in SNP order.
-    Blocks are padded to ceil(p/world) rows so one all_gather moves everything (a single small message per rank)."""
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(), dist.get_rank()
+def unpack_gathered(host_bytes, p, world):
+    """The all-gathered buffer (world blocks of ceil(p/world) rows, rank order) -> the six columns of all p SNPs in SNP order."""
     cols = int(np.ceil(p / world))
-    buf = torch.zeros((cols, 8), dtype=torch.float32, device=device)
-    t = torch.as_tensor(rows_local, dtype=torch.float32, device=device)
-    buf[: t.shape[0]] = t
-    out = torch.empty((world * cols, 8), dtype=torch.float32, device=device)
-    dist.all_gather_into_tensor(out, buf)
-    full = out.cpu().numpy()
-    keep = np.concatenate([np.arange(r * cols, r * cols + (shard_range(p, r, world)[1] - shard_range(p, r, world)[0]))
-                           for r in range(world)])
-    return full[keep]
+    parts = []
+    for r in range(world):
+        a, b = shard_range(p, r, world)
+        parts.append(unpack_block(host_bytes[32 * cols * r:32 * cols * (r + 1)], cols, b - a))
+    return {k: np.concatenate([q[k] for q in parts]) for k in parts[0]}

@@ -54,8 +54,13 @@ def test_assoc_vs_oracle_and_reference(name, grid, ctx):
     for col in ["beta", "se_beta", "tau", "lambda", "F_wald"]:
         ref = z[f"{tag}_{col}"]
         rowbad |= bits(got[col].astype(ref.dtype)) != bits(ref)
-    assert rowbad.mean() <= 0.01
+    assert rowbad.mean() <= 0.01, int(rowbad.sum())
     np.testing.assert_allclose(got["p_wald"], z[f"{tag}_p_wald"], rtol=1e-8)
+    # the rows that are not bit-identical (none today) stay within the Tier-A tolerances, as the CPU twin of
+    # this test asserts for the oracle (tests/test_oracle_golden.py): every column, unconditionally on the bad rows
+    for col, tol in (("beta", 1e-4), ("se_beta", 1e-4), ("tau", 1e-4), ("lambda", 2e-5), ("F_wald", 2e-4)):
+        np.testing.assert_allclose(np.asarray(got[col], np.float64)[rowbad], np.asarray(z[f"{tag}_{col}"], np.float64)[rowbad],
+                                   rtol=tol, err_msg=col)
 
 
 def test_fdist_sf_device_vs_scipy_fixture(ctx):

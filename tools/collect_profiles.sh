@@ -2,7 +2,7 @@
 # Collect the round's judged measurements on the GPU box (run through gpurun from the repo root):
 #   the bench line, rocprofv3 --kernel-trace --stats of the SAME bench command, and PMC passes (one counter group per run) ON bench.py
 #   ITSELF (the eigensolver is skipped in those through --eigh-cache: counter mode + its dispatch depth, profiles/r02_pmc_abort_diagnosis.txt;
-#   one pass also runs WITH the eigensolver under PG_SYEVD_PANEL_SYNC to show that bench.py is profilable end to end).
+#   one pass also runs WITH the eigensolver (the library drains the stream once per panel) to show that bench.py is profilable end to end).
 # Outputs under gpurun_out/prof_${TAG}_final/ ; tools/summarize_prof.py condenses them into profiles/.
 set -o pipefail
 TAG=${1:-r02}
@@ -27,7 +27,7 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass sq_valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 pass sq_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES
-# bench.py WITH the eigensolver under the counter mode (bench.py sets PG_SYEVD_PANEL_SYNC itself when it sees the profiler)
+# bench.py WITH the eigensolver under the counter mode (the library bounds the queue depth itself since r3)
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_WAVES --output-format csv -d $OUT/pmc_full -o c -- python3 $ROOT/bench.py --steps 1 --warmup 0 --e2e 0 --cpu-sample 0 > $OUT/pmc_full.json 2> $OUT/pmc_full.log
 echo "pmc_full rc=$?"
 rm -f $CACHE

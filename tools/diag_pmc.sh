@@ -1,8 +1,11 @@
 #!/bin/bash
 # Diagnosis of the round-1 "rocprofv3 --pmc aborts on bench.py" report.  Finding (profiles/r02_pmc_abort_diagnosis.txt):
 # the SIGSEGV is inside librocprofiler-sdk's hsa intercept, reached from a hipLaunchKernel of the tridiagonalisation loop, once
-# ~10^4 dispatches are in flight without a synchronisation; PG_SYEVD_PANEL_SYNC=1 (drain the stream once per panel) avoids it.
-# This script reproduces both sides: counter mode on the eigensolver at n = 10 000 without and with the knob.
+# ~10^4 dispatches are in flight without a synchronisation; draining the stream once per panel avoids it — since round 3 the
+# library does that for every caller.  By default this script runs the fixed configuration only (counter mode on the eigensolver
+# at n = 10 000).  `diag_pmc.sh reproduce` first re-runs the known-crashing deep-queue configuration (PG_SYEVD_PANEL_SYNC=0): that
+# deliberately SIGSEGVs a GPU process on a shared box — the committed diagnosis file is the evidence, do not run it in routine
+# collection or soak scripts.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmcdiag
 mkdir -p $OUT
@@ -18,10 +21,10 @@ step() {  # name seconds cmd...
   return 0
 }
 PMC="rocprofv3 --kernel-trace --pmc SQ_WAVES --output-format csv"
-if [ "$1" != "fixed-only" ]; then
-  step pmc_syevd10k_deep_queue 500 $PMC -d $OUT/pmc_syevd10k -o c -- python3 $ROOT/tools/diag_pmc2.py syevd 10000
+if [ "$1" = "reproduce" ]; then
+  PG_SYEVD_PANEL_SYNC=0 step pmc_syevd10k_deep_queue 500 $PMC -d $OUT/pmc_syevd10k -o c -- python3 $ROOT/tools/diag_pmc2.py syevd 10000
 fi
-export PG_SYEVD_PANEL_SYNC=1
+unset PG_SYEVD_PANEL_SYNC
 step pmc_syevd10k_panel_sync 500 $PMC -d $OUT/pmc_syevd10k_sync -o c -- python3 $ROOT/tools/diag_pmc2.py syevd 10000
 find $OUT -name "*.db" -delete
 find $OUT -name "*.csv" -size +2M -delete
