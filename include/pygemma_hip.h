@@ -265,6 +265,15 @@ int pgx_dgemm_dev(pg_ctx *ctx, int transA, int64_t M, int64_t N, int64_t K, doub
                   const double *B, int64_t ldb, double beta, double *C, int64_t ldc);
 int pgx_sytrd_dev(pg_ctx *ctx, int64_t n, const float *K, double *d, double *e, double *tau, double *Vall);
 int pgx_stedc_dev(pg_ctx *ctx, int64_t n, const double *d_host, const double *e_host, double *evals_host, double *Z_dev);
+/* The two-stage tridiagonalisation of pg_syevd_dev (csrc/sb2.hip), one stage at a time (all matrices n x n fp64 row-major on the device):
+ * pgx_sb2_stage1_dev : lower triangle of float32 K -> Aband (the band |i - j| <= 64 of the result is the band matrix Q1' K Q1);
+ *                      Z, if given, is replaced by Q1 Z.  flags (host, 4 ints): [0] a panel needed the one-stage fallback.
+ * pgx_sb2_stage2_dev : band |i - j| <= 64 of Aband (lower part read) -> tridiagonal d (n), e (n - 1) on the device by bulge chasing;
+ *                      Z, if given, is replaced by Q2 Z.  flags: [1] a wait inside the bulge-chasing kernel expired. */
+int pgx_sb2_stage1_dev(pg_ctx *ctx, int64_t n, const float *K, double *Aband, double *Z, int *flags);
+int pgx_sb2_stage2_dev(pg_ctx *ctx, int64_t n, const double *Aband, double *d, double *e, double *Z, int *flags);
+/* debugging aid: host-mapped memory (pg_host_alloc, >= 4 ints) in which the bulge-chasing kernel records (sweep, step, phase); NULL = off */
+int pgx_sb2_set_debug(void *host_mapped);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ SYMBOLS = [
     "pg_memcpy_d2d_async", "pg_memcpy2d_h2d_async", "pg_stage_rows", "pg_event_sync", "pg_stream_wait_event",
     "pg_comm_unique_id", "pg_comm_init_rank", "pg_comm_init_all", "pg_comm_destroy", "pg_comm_size", "pg_comm_rank",
     "pg_comm_broadcast_dev", "pg_comm_allgather_dev", "pg_comm_allreduce_f64_dev", "pg_comm_barrier", "pg_comm_group_start",
-    "pg_comm_group_end", "pgx_dgemm_dev", "pgx_sytrd_dev", "pgx_stedc_dev", "pg_kinship_geno_dev", "pg_assoc_lrt_dev", "pg_rotate_auto_dev", "pg_assoc_set_eval_trace", "pg_rotate_auto_i8_dev",
+    "pg_comm_group_end", "pgx_dgemm_dev", "pgx_sytrd_dev", "pgx_stedc_dev", "pgx_sb2_stage1_dev", "pgx_sb2_stage2_dev", "pgx_sb2_set_debug", "pg_kinship_geno_dev", "pg_assoc_lrt_dev", "pg_rotate_auto_dev", "pg_assoc_set_eval_trace", "pg_rotate_auto_i8_dev",
 ]
 
 
@@ -127,11 +127,14 @@ def load():
     L.pgx_dgemm_dev.argtypes = [vp, i32, i64, i64, i64, C.c_double, vp, i64, vp, i64, C.c_double, vp, i64]
     L.pgx_sytrd_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     L.pgx_stedc_dev.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.pgx_sb2_stage1_dev.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.pgx_sb2_stage2_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    L.pgx_sb2_set_debug.argtypes = [vp]
     for name in ("pg_host_alloc", "pg_host_free", "pg_host_register", "pg_host_unregister", "pg_memcpy_h2d_async", "pg_memcpy_d2h_async",
                  "pg_memcpy_d2d_async", "pg_memcpy2d_h2d_async", "pg_stage_rows", "pg_event_sync", "pg_stream_wait_event", "pg_comm_unique_id",
                  "pg_comm_init_rank", "pg_comm_init_all", "pg_comm_destroy", "pg_comm_size", "pg_comm_rank", "pg_comm_broadcast_dev",
                  "pg_comm_allgather_dev", "pg_comm_allreduce_f64_dev", "pg_comm_barrier", "pg_comm_group_start", "pg_comm_group_end",
-                 "pgx_dgemm_dev", "pgx_sytrd_dev", "pgx_stedc_dev"):
+                 "pgx_dgemm_dev", "pgx_sytrd_dev", "pgx_stedc_dev", "pgx_sb2_stage1_dev", "pgx_sb2_stage2_dev", "pgx_sb2_set_debug"):
         getattr(L, name).restype = i32
     for name in ("pg_ctx_create", "pg_ctx_create_on_stream", "pg_ctx_sync", "pg_ctx_device", "pg_malloc", "pg_free",
                  "pg_memcpy_h2d", "pg_memcpy_d2h", "pg_memset", "pg_assoc_dev", "pg_assoc", "pg_fdist_sf_dev",

@@ -1,13 +1,16 @@
-// dgemm.hpp — fp64 MFMA GEMM (v_mfma_f64_16x16x4_f64) used by the eigensolver: the syr2k trailing update
-// of the Householder tridiagonalisation, the divide-and-conquer merges and the back-transformation.
+// dgemm.hpp — fp64 MFMA GEMM (v_mfma_f64_16x16x4_f64) used by the eigensolver: the rank-2b trailing updates of the band
+// reduction and of the Householder tridiagonalisation, the divide-and-conquer merges and the back-transformations.
 //
-//   C (MxN, row-major, ldc) = alpha * op(A) * B + beta * C
+//   C (MxN, row-major, ldc) = alpha * op(A) * op(B) + beta * C
 //   TA = false : A is M x K row-major (lda)            TA = true : A is stored K x M row-major (lda)
-//   B is K x N row-major (ldb)
+//   TB = false : B is K x N row-major (ldb)            TB = true : B is stored N x K row-major (ldb); its k index may be
+//                                                                 XOR-ed with kxorB (a multiple of 4): [V W] read as [W V]
+//   batch      : blockIdx.z = batch index z; operands advance by strideA/B/C elements per z; the LAST batch element may
+//                have fewer rows (M_last) and a shorter K (K_last) — the clipped bottom block of a wavefront of reflector blocks
 //
-// 128x128x8 tile per 256-thread workgroup (4 waves as 2x2, each 4x4 MFMA tiles of 16x16), LDS tiles kept
-// K-major ([k][m], [k][n]) so a wave's operand read is 16 consecutive doubles per k-row; rows padded by 16
-// doubles so the four k-rows a ds_read_b64 touches fall on disjoint bank halves.  f64 MFMA lane maps:
+// (32 WMI)x128x8 tile per 256-thread workgroup (4 waves as 2x2, each WMI x 4 MFMA tiles of 16x16; WMI = 4: 128 rows, WMI = 2:
+// 64 rows for outputs with M <= 64), LDS tiles kept K-major ([k][m], [k][n]) so a wave's operand read is 16 consecutive doubles
+// per k-row; rows padded by 16 doubles so the four k-rows a ds_read_b64 touches fall on disjoint bank halves.  f64 MFMA lane maps:
 // A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], C/D col = l&15, row = (l>>4) + 4*reg.
 #pragma once
 #include "common.hpp"
@@ -21,7 +24,7 @@ typedef double doublex4 __attribute__((ext_vector_type(4)));
 #ifndef PG_DBK
 #define PG_DBK 8
 #endif
-constexpr int DBM = 128, DBN = 128, DBK = PG_DBK, DPAD = 16, DPASS = DBK / 8;   // staging works in passes of 8 k-rows
+constexpr int DBN = 128, DBK = PG_DBK, DPAD = 16, DPASS = DBK / 8;   // staging works in passes of 8 k-rows
 
 struct DgemmParams {
     long long M, N, K, lda, ldb, ldc;
@@ -33,33 +36,46 @@ struct DgemmParams {
     int ksplit;       // > 1: blockIdx.y owns a K range and writes a partial MxN slab to ws (summed by splitk_reduce_kernel)
     long long kchunk;
     double *ws;
+    // extensions (all zero for a plain call)
+    int kxorB;                              // TB only
+    int nbatch;                             // >= 1
+    long long strideA, strideB, strideC;    // elements per batch index
+    long long M_last, K_last;               // dimensions of batch element nbatch - 1 (0: same as M / K)
 };
 
-template <bool TA>
+template <bool TA, bool TB, int WMI>
 __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
 {
+    constexpr int DBM = 32 * WMI;
     __shared__ double As[2][DBK][DBM + DPAD];
     __shared__ double Bs[2][DBK][DBN + DPAD];
+    const int z = blockIdx.z;
+    const bool lastz = (z == gp.nbatch - 1);
+    const long long M = (lastz && gp.M_last > 0) ? gp.M_last : gp.M;
+    const long long Kfull = (lastz && gp.K_last > 0) ? gp.K_last : gp.K;
+    const double *Ap = gp.A + (long long)z * gp.strideA, *Bp = gp.B + (long long)z * gp.strideB;
+    double *Cp = gp.C + (long long)z * gp.strideC;
     const int tiles_n = (int)((gp.N + DBN - 1) / DBN);
     const long long m0 = (long long)(blockIdx.x / tiles_n) * DBM, n0 = (long long)(blockIdx.x % tiles_n) * DBN;
+    if (m0 >= M) return;
     if (gp.lower && n0 >= m0 + DBM) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
 
-    doublex4 acc[4][4];
+    doublex4 acc[WMI][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < WMI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int e = 0; e < 4; e++) acc[i][j][e] = 0.0;
 
-    const long long kbeg_ = (gp.ksplit > 1) ? (long long)blockIdx.y * gp.kchunk : 0;
-    const long long KEND = (gp.ksplit > 1) ? ((kbeg_ + gp.kchunk < gp.K) ? kbeg_ + gp.kchunk : gp.K) : gp.K;
+    const long long kbeg = (gp.ksplit > 1) ? (long long)blockIdx.y * gp.kchunk : 0;
+    const long long KEND = (gp.ksplit > 1) ? ((kbeg + gp.kchunk < Kfull) ? kbeg + gp.kchunk : Kfull) : Kfull;
     double ra[DPASS][4], rb[DPASS][4];
     // interior tiles with 16-byte-aligned operands take two double2 loads per operand; edges go element-wise
     const bool fastB = gp.vecB && (n0 + DBN <= gp.N);
-    const bool fastA = gp.vecA && (m0 + DBM <= gp.M);
+    const bool fastA = gp.vecA && (m0 + DBM <= M);
     auto load4d = [&](const double *p, double (&r)[4]) {
         const double2 u = *reinterpret_cast<const double2 *>(p), w = *reinterpret_cast<const double2 *>(p + 2);
         r[0] = u.x; r[1] = u.y; r[2] = w.x; r[3] = w.y;
@@ -68,29 +84,41 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
 #pragma unroll
         for (int ps = 0; ps < DPASS; ps++) {
             const long long k0 = kbase + 8 * ps;
-            // B tile: 8 rows (k) x 128 cols: thread -> row tid/32, 4 consecutive cols
-            {
-                const long long kr = k0 + (tid >> 5), col = n0 + (tid & 31) * 4;
-                if (fastB && kr < KEND) load4d(gp.B + kr * gp.ldb + col, rb[ps]);
+            if (TB) {
+                // B tile: 128 rows (n) x 8 (k): thread -> row tid/2, 4 consecutive k (k index XOR-ed as a block of 4)
+                const long long row = n0 + (tid >> 1), kc = k0 + (tid & 1) * 4, kp = kc ^ (long long)gp.kxorB;
+                if (fastB && kc + 3 < KEND) load4d(Bp + row * gp.ldb + kp, rb[ps]);
                 else {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) rb[ps][q] = (kr < KEND && col + q < gp.N) ? gp.B[kr * gp.ldb + col + q] : 0.0;
+                    for (int q = 0; q < 4; q++) rb[ps][q] = (row < gp.N && kc + q < KEND) ? Bp[row * gp.ldb + kp + q] : 0.0;
+                }
+            } else {
+                // B tile: 8 rows (k) x 128 cols: thread -> row tid/32, 4 consecutive cols
+                const long long kr = k0 + (tid >> 5), col = n0 + (tid & 31) * 4;
+                if (fastB && kr < KEND) load4d(Bp + kr * gp.ldb + col, rb[ps]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) rb[ps][q] = (kr < KEND && col + q < gp.N) ? Bp[kr * gp.ldb + col + q] : 0.0;
                 }
             }
             if (TA) {
                 const long long kr = k0 + (tid >> 5), col = m0 + (tid & 31) * 4;
-                if (fastA && kr < KEND) load4d(gp.A + kr * gp.lda + col, ra[ps]);
-                else {
+                if ((tid & 31) * 4 < DBM) {
+                    if (fastA && kr < KEND) load4d(Ap + kr * gp.lda + col, ra[ps]);
+                    else {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) ra[ps][q] = (kr < KEND && col + q < gp.M) ? gp.A[kr * gp.lda + col + q] : 0.0;
+                        for (int q = 0; q < 4; q++) ra[ps][q] = (kr < KEND && col + q < M) ? Ap[kr * gp.lda + col + q] : 0.0;
+                    }
                 }
             } else {
-                // A tile: 128 rows (m) x 8 (k): thread -> row tid/2, 4 consecutive k
+                // A tile: DBM rows (m) x 8 (k): thread -> row tid/2, 4 consecutive k
                 const long long row = m0 + (tid >> 1), kc = k0 + (tid & 1) * 4;
-                if (fastA && kc + 3 < KEND) load4d(gp.A + row * gp.lda + kc, ra[ps]);
-                else {
+                if ((tid >> 1) < DBM) {
+                    if (fastA && kc + 3 < KEND) load4d(Ap + row * gp.lda + kc, ra[ps]);
+                    else {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) ra[ps][q] = (row < gp.M && kc + q < KEND) ? gp.A[row * gp.lda + kc + q] : 0.0;
+                        for (int q = 0; q < 4; q++) ra[ps][q] = (row < M && kc + q < KEND) ? Ap[row * gp.lda + kc + q] : 0.0;
+                    }
                 }
             }
         }
@@ -98,23 +126,32 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int ps = 0; ps < DPASS; ps++) {
+            if (TB) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) Bs[buf][8 * ps + (tid >> 5)][(tid & 31) * 4 + q] = rb[ps][q];
-            if (TA) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) As[buf][8 * ps + (tid >> 5)][(tid & 31) * 4 + q] = ra[ps][q];
+                for (int q = 0; q < 4; q++) Bs[buf][8 * ps + (tid & 1) * 4 + q][tid >> 1] = rb[ps][q];
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; q++) As[buf][8 * ps + (tid & 1) * 4 + q][tid >> 1] = ra[ps][q];
+                for (int q = 0; q < 4; q++) Bs[buf][8 * ps + (tid >> 5)][(tid & 31) * 4 + q] = rb[ps][q];
+            }
+            if (TA) {
+                if ((tid & 31) * 4 < DBM) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) As[buf][8 * ps + (tid >> 5)][(tid & 31) * 4 + q] = ra[ps][q];
+                }
+            } else {
+                if ((tid >> 1) < DBM) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) As[buf][8 * ps + (tid & 1) * 4 + q][tid >> 1] = ra[ps][q];
+                }
             }
         }
     };
 
-    const long long kbeg = (gp.ksplit > 1) ? (long long)blockIdx.y * gp.kchunk : 0;
-    const long long kend = (gp.ksplit > 1) ? ((kbeg + gp.kchunk < gp.K) ? kbeg + gp.kchunk : gp.K) : gp.K;
-    const int KT = (int)((kend - kbeg + DBK - 1) / DBK);
-    gload(kbeg);
-    lstore(0);
+    const int KT = (int)((KEND - kbeg + DBK - 1) / DBK);
+    if (KT > 0) {
+        gload(kbeg);
+        lstore(0);
+    }
     __syncthreads();
     for (int kt = 0; kt < KT; kt++) {
         const int buf = kt & 1;
@@ -122,13 +159,13 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
 #pragma unroll
         for (int kk = 0; kk < DBK; kk += 4) {
             const int kr = kk + (lane >> 4);
-            double a[4], b[4];
+            double a[WMI], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = As[buf][kr][wm * 64 + i * 16 + (lane & 15)];
+            for (int i = 0; i < WMI; i++) a[i] = As[buf][kr][wm * (16 * WMI) + i * 16 + (lane & 15)];
 #pragma unroll
             for (int j = 0; j < 4; j++) b[j] = Bs[buf][kr][wn * 64 + j * 16 + (lane & 15)];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < WMI; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
@@ -136,18 +173,18 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < WMI; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const long long col = n0 + wn * 64 + j * 16 + (lane & 15);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const long long row = m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * e;
-                if (row < gp.M && col < gp.N) {
+                const long long row = m0 + wm * (16 * WMI) + i * 16 + (lane >> 4) + 4 * e;
+                if (row < M && col < gp.N) {
                     if (gp.ksplit > 1) {
                         gp.ws[((size_t)blockIdx.y * gp.M + row) * gp.N + col] = acc[i][j][e];
                     } else {
-                        double *c = gp.C + row * gp.ldc + col;
+                        double *c = Cp + row * gp.ldc + col;
                         double v = gp.alpha * acc[i][j][e];
                         if (gp.beta != 0.0) v += gp.beta * (*c);
                         *c = v;
@@ -157,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
         }
 }
 
-__global__ void splitk_reduce_kernel(long long M, long long N, int ksplit, const double *ws, double alpha, double beta, double *C, long long ldc)
+static __global__ void splitk_reduce_kernel(long long M, long long N, int ksplit, const double *ws, double alpha, double beta, double *C, long long ldc)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * N) return;
@@ -169,37 +206,76 @@ __global__ void splitk_reduce_kernel(long long M, long long N, int ksplit, const
     *c = v;
 }
 
-inline int dgemm(pg_ctx *ctx, bool transA, long long M, long long N, long long K, double alpha, const double *A, long long lda,
-                 const double *B, long long ldb, double beta, double *C, long long ldc, bool lower_only = false)
+// full descriptor form; dgemm() below is the plain call
+struct DgemmDesc {
+    bool transA = false, transB = false;
+    long long M = 0, N = 0, K = 0;
+    double alpha = 1.0, beta = 0.0;
+    const double *A = nullptr, *B = nullptr;
+    double *C = nullptr;
+    long long lda = 0, ldb = 0, ldc = 0;
+    bool lower_only = false;
+    int kxorB = 0;
+    int nbatch = 1;
+    long long strideA = 0, strideB = 0, strideC = 0, M_last = 0, K_last = 0;
+    bool allow_splitk = true;
+};
+
+inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
 {
-    if (M <= 0 || N <= 0) return PG_OK;
-    DgemmParams gp{M, N, K, lda, ldb, ldc, A, B, C, alpha, beta, 0, 0, lower_only ? 1 : 0, 1, K, nullptr};
-    gp.vecA = ((uintptr_t)A % 16 == 0) && (lda % 2 == 0);
-    gp.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 2 == 0);
-    const long long tiles = ((M + DBM - 1) / DBM) * ((N + DBN - 1) / DBN);
-    // skinny output with a long K (V'V, V'Z of the back-transformation): too few tiles to fill 256 CUs -> split K
+    if (d.M <= 0 || d.N <= 0 || d.nbatch <= 0) return PG_OK;
+    DgemmParams gp{};
+    gp.M = d.M; gp.N = d.N; gp.K = d.K; gp.lda = d.lda; gp.ldb = d.ldb; gp.ldc = d.ldc;
+    gp.A = d.A; gp.B = d.B; gp.C = d.C; gp.alpha = d.alpha; gp.beta = d.beta;
+    gp.lower = d.lower_only ? 1 : 0; gp.ksplit = 1; gp.kchunk = d.K; gp.ws = nullptr;
+    gp.kxorB = d.transB ? d.kxorB : 0; gp.nbatch = d.nbatch;
+    gp.strideA = d.strideA; gp.strideB = d.strideB; gp.strideC = d.strideC; gp.M_last = d.M_last; gp.K_last = d.K_last;
+    gp.vecA = ((uintptr_t)d.A % 16 == 0) && (d.lda % 2 == 0) && (d.strideA % 2 == 0);
+    gp.vecB = ((uintptr_t)d.B % 16 == 0) && (d.ldb % 2 == 0) && (d.strideB % 2 == 0);
+    const bool small_m = d.M <= 64;
+    const int dbm = small_m ? 64 : 128;
+    const long long tiles = ((d.M + dbm - 1) / dbm) * ((d.N + DBN - 1) / DBN);
+    // skinny output with a long K (V'V, V'Z of the back-transformation, the panel Grams): too few tiles to fill 256 CUs -> split K
     int ksplit = 1;
-    if (tiles < 256 && K >= 1024) {
-        ksplit = (int)std::min<long long>((768 + tiles - 1) / tiles, K / 256);
+    if (d.allow_splitk && d.nbatch == 1 && tiles < 256 && d.K >= 1024) {
+        ksplit = (int)std::min<long long>((768 + tiles - 1) / tiles, d.K / 256);
         if (ksplit < 2) ksplit = 1;
     }
     if (ksplit > 1) {
-        long long kchunk = (K + ksplit - 1) / ksplit;
+        long long kchunk = (d.K + ksplit - 1) / ksplit;
         kchunk = (kchunk + DBK - 1) / DBK * DBK;            // keep 16-byte alignment of the K offset
-        ksplit = (int)((K + kchunk - 1) / kchunk);
-        int rc = ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, (size_t)ksplit * M * N * sizeof(double));
+        ksplit = (int)((d.K + kchunk - 1) / kchunk);
+        int rc = ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, (size_t)ksplit * d.M * d.N * sizeof(double));
         if (rc) return rc;
         gp.ksplit = ksplit; gp.kchunk = kchunk; gp.ws = (double *)ctx->scratch;
     }
-    dim3 grid((unsigned)tiles, (unsigned)ksplit);
-    if (transA) dgemm_kernel<true><<<grid, 256, 0, ctx->stream>>>(gp);
-    else dgemm_kernel<false><<<grid, 256, 0, ctx->stream>>>(gp);
+    dim3 grid((unsigned)tiles, (unsigned)ksplit, (unsigned)d.nbatch);
+    hipStream_t st = ctx->stream;
+#define PG_DG_LAUNCH(TA_, TB_)                                                               \
+    do {                                                                                     \
+        if (small_m) dgemm_kernel<TA_, TB_, 2><<<grid, 256, 0, st>>>(gp);                    \
+        else dgemm_kernel<TA_, TB_, 4><<<grid, 256, 0, st>>>(gp);                            \
+    } while (0)
+    if (d.transA && d.transB) PG_DG_LAUNCH(true, true);
+    else if (d.transA) PG_DG_LAUNCH(true, false);
+    else if (d.transB) PG_DG_LAUNCH(false, true);
+    else PG_DG_LAUNCH(false, false);
+#undef PG_DG_LAUNCH
     PG_HIP(hipGetLastError());
     if (ksplit > 1) {
-        splitk_reduce_kernel<<<(unsigned)((M * N + 255) / 256), 256, 0, ctx->stream>>>(M, N, ksplit, gp.ws, alpha, beta, C, ldc);
+        splitk_reduce_kernel<<<(unsigned)((d.M * d.N + 255) / 256), 256, 0, st>>>(d.M, d.N, ksplit, gp.ws, d.alpha, d.beta, d.C, d.ldc);
         PG_HIP(hipGetLastError());
     }
     return PG_OK;
+}
+
+inline int dgemm(pg_ctx *ctx, bool transA, long long M, long long N, long long K, double alpha, const double *A, long long lda,
+                 const double *B, long long ldb, double beta, double *C, long long ldc, bool lower_only = false)
+{
+    DgemmDesc d;
+    d.transA = transA; d.M = M; d.N = N; d.K = K; d.alpha = alpha; d.beta = beta;
+    d.A = A; d.lda = lda; d.B = B; d.ldb = ldb; d.C = C; d.ldc = ldc; d.lower_only = lower_only;
+    return dgemm_ex(ctx, d);
 }
 
 }  // namespace pg

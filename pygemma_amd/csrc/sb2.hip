@@ -1,0 +1,776 @@
+// sb2.hip — H1 (lmm/lmm.py:151-162 / :196-207: the reference calls scipy.linalg.eigh): the TWO-STAGE tridiagonalisation of the
+// fp64 eigensolver, written for gfx950.  The one-stage reduction of syevd.hip reads the whole trailing matrix once per column
+// (HBM-bound, ~3 launches per column); here almost all the work is fp64-MFMA GEMM:
+//
+//   stage 1  dense -> band of half-width b = 64.  Per panel of 64 columns: tall-skinny QR by CholeskyQR2 (two Gram GEMMs + two
+//            64 x 64 Cholesky factorisations, the orthogonality of the first pass checked on the second Gram), its Householder
+//            form (V unit lower trapezoidal, T) rebuilt from Q by an LU factorisation of E - Q D without pivoting (Ballard et al.,
+//            "Reconstructing Householder vectors from TSQR"), then the two-sided block update A22 -= V W' + W V' as ONE GEMM of
+//            depth 2b with operands [V W] and [W V] (the second read from the first with its k index XOR-ed by 64).
+//            A panel that CholeskyQR2 cannot factor to working accuracy (rank-deficient K) raises a device flag; the caller then
+//            solves with the one-stage path.
+//   stage 2  band -> tridiagonal by bulge chasing in ONE persistent kernel: workgroups take sweeps from a queue in order; a step
+//            (sweep s, block k) owns the 64 rows r0 = s + 1 + 64 k .. of the compact band and (1) applies the previous step's
+//            reflector from the right, (2) forms its own reflector from the first column, (3) applies it from the left and
+//            (4) on both sides of the diagonal block — all in LDS; step (s + 1, k) waits for (s, k + 1) through a per-sweep
+//            progress word (write-through stores, drained, then the flag: the hand-off of the MI355X guide's Guideline 16).
+//   back     U = Q1 (Q2 Z).  Q2: the length-64 reflectors of 64 consecutive sweeps at one block index form a 127 x 64 parallelogram
+//            with a compact-WY factor; blocks on an anti-diagonal (group, block index) wavefront touch disjoint rows 128 apart,
+//            so each wavefront is two batched GEMMs.  Q1: blocks of 256 reflectors as in the one-stage solver.
+#include "sb2.hpp"
+#include "dgemm.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+
+namespace pg {
+
+constexpr int B = SB_B;          // 64
+constexpr int P65 = B + 1;       // LDS pitch of a 64 x 64 matrix
+constexpr int MAT = B * P65;     // doubles per LDS matrix
+constexpr int BT1_BLOCK = 256;   // reflectors per block of the stage-1 back-transformation
+
+// small matrices in w.sm (b x b each)
+enum { SM_G1 = 0, SM_R1, SM_R1INV, SM_G2, SM_XM, SM_M1, SM_M2, SM_COUNT };
+
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double wave_sum64(double v)
+{
+    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+// ---- 64 x 64 building blocks on LDS matrices [64][65], 256 threads -----------------------------------------------------------
+// upper Cholesky factor in place: A = R'R (upper triangle of A in, R out, strict lower part zeroed).  Returns false (to every
+// thread) when a pivot is not positive / not finite; the factorisation then continues on a substitute pivot so that nothing
+// downstream sees a NaN it did not bring itself.
+__device__ bool chol_upper64(double *A, int tid)
+{
+    bool ok = true;
+    for (int k = 0; k < B; k++) {
+        const double akk = A[k * P65 + k];
+        const bool bad = !(akk > 0.0) || !(akk < 1.0e300);
+        const double d = bad ? 1.0 : sqrt(akk);
+        ok = ok && !bad;
+        __syncthreads();
+        if (tid < B) {
+            const int j = tid;
+            if (j == k) A[k * P65 + k] = d;
+            else if (j > k) A[k * P65 + j] /= d;
+            else A[k * P65 + j] = 0.0;     // (row k, column j < k): strict lower part
+        }
+        __syncthreads();
+        const int i = tid >> 2, j0 = (tid & 3) * 16;
+        if (i > k) {
+            const double aki = A[k * P65 + i];
+#pragma unroll 4
+            for (int j = j0; j < j0 + 16; j++)
+                if (j >= i) A[i * P65 + j] -= aki * A[k * P65 + j];
+        }
+        __syncthreads();
+    }
+    return ok;
+}
+
+// X U = Bm for X (64 x 64), U upper triangular: row i of X by forward substitution along j, four lanes per row splitting the
+// inner product.  ucoef(k, j) = U[k][j] for k < j, udiag(j) = U[j][j], rhs(i, j) = Bm[i][j].  All 256 threads call.
+template <class UC, class UD, class RH>
+__device__ void solve_right_upper64(double *X, UC ucoef, UD udiag, RH rhs, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = 16 * wave + (lane >> 2), part = lane & 3;
+    for (int j = 0; j < B; j++) {
+        double s = 0.0;
+        for (int k = part; k < j; k += 4) s = fma(X[i * P65 + k], ucoef(k, j), s);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (part == 0) X[i * P65 + j] = (rhs(i, j) - s) / udiag(j);
+        wave_sync_lds();
+    }
+    __syncthreads();
+}
+
+// C = A Bm (64 x 64 x 64) from LDS operands given by accessors; out(i, j, value) consumes the result
+template <class FA, class FB, class OUT>
+__device__ void mm64(FA a, FB b, OUT out, int tid)
+{
+    const int i = tid >> 2, j0 = (tid & 3) * 16;
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0.0;
+    for (int k = 0; k < B; k++) {
+        const double aik = a(i, k);
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[q] = fma(aik, b(k, j0 + q), acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) out(i, j0 + q, acc[q]);
+}
+
+__device__ __forceinline__ void load64(double *dst, const double *src, long long ld, int tid)
+{
+    const int i = tid >> 2, j0 = (tid & 3) * 16;
+#pragma unroll
+    for (int q = 0; q < 16; q++) dst[i * P65 + j0 + q] = src[(long long)i * ld + j0 + q];
+}
+
+// ---- pass 1 of CholeskyQR2: G -> R1 (upper) and R1^-1 -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chol_inv_kernel(const double *G, double *R, double *Rinv, int *fail)
+{
+    extern __shared__ double lds[];
+    double *A = lds, *X = lds + MAT;
+    const int tid = threadIdx.x;
+    load64(A, G, B, tid);
+    __syncthreads();
+    const bool ok = chol_upper64(A, tid);
+    if (!ok && tid == 0) atomicOr(fail, 1);
+    solve_right_upper64(X, [&](int k, int j) { return A[k * P65 + j]; }, [&](int j) { return A[j * P65 + j]; },
+                        [&](int i, int j) { return i == j ? 1.0 : 0.0; }, tid);
+    const int i = tid >> 2, j0 = (tid & 3) * 16;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        R[i * B + j0 + q] = A[i * P65 + j0 + q];
+        Rinv[i * B + j0 + q] = X[i * P65 + j0 + q];
+    }
+}
+
+// ---- pass 2 + Householder reconstruction ------------------------------------------------------------------------------------
+// in : G2 = Q1'Q1, R1, Q1top = first 64 rows of Q1 (ld 64)
+// out: Rs = D R2 R1 into the band block Aband (ld lda; only the upper triangle is written), V's top block (unit lower) into VW (ld 2b)
+//      and Vst (ld ldv), T (64 x 64), Xm = -R2^-1 D U^-1 (so that the rows of V below the top block are Q1 Xm)
+__global__ __launch_bounds__(256) void recon_kernel(const double *G2, const double *R1g, const double *Q1top, double *Aband, long long lda,
+                                                    double *VW, double *Vst, long long ldv, double *Tout, double *Xm, int *fail)
+{
+    extern __shared__ double lds[];
+    double *M0 = lds, *M1 = lds + MAT, *M2 = lds + 2 * MAT, *M3 = lds + 3 * MAT;
+    __shared__ double Dg[B], piv[B];
+    __shared__ double red[4];
+    const int tid = threadIdx.x, i = tid >> 2, j0 = (tid & 3) * 16;
+    // orthogonality of pass 1 = |G2 - I|_max: CholeskyQR2 reaches working accuracy when this is well below 1
+    double err = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const double g = G2[i * B + j0 + q];
+        M0[i * P65 + j0 + q] = g;
+        const double dlt = fabs(g - ((i == j0 + q) ? 1.0 : 0.0));
+        err = (dlt > err || !(dlt == dlt)) ? dlt : err;      // a NaN sticks
+    }
+    for (int s = 1; s < 64; s <<= 1) { const double o = __shfl_xor(err, s, 64); err = (o > err || !(o == o)) ? o : err; }
+    if ((tid & 63) == 0) red[tid >> 6] = err;
+    __syncthreads();
+    if (tid == 0) {
+        double e = red[0];
+        for (int w = 1; w < 4; w++) e = (red[w] > e || !(red[w] == red[w])) ? red[w] : e;
+        if (!(e <= 0.05)) atomicOr(fail, 1);
+    }
+    const bool ok = chol_upper64(M0, tid);                                        // M0 = R2
+    if (!ok && tid == 0) atomicOr(fail, 1);
+    solve_right_upper64(M1, [&](int k, int j) { return M0[k * P65 + j]; }, [&](int j) { return M0[j * P65 + j]; },
+                        [&](int a, int b) { return a == b ? 1.0 : 0.0; }, tid);   // M1 = R2^-1
+    mm64([&](int a, int k) { return Q1top[a * B + k]; }, [&](int k, int b) { return M1[k * P65 + b]; },
+         [&](int a, int b, double v) { M2[a * P65 + b] = v; }, tid);               // M2 = top block of Q = Q1 R2^-1
+    load64(M3, R1g, B, tid);                                                      // M3 = R1
+    __syncthreads();
+    // LU of E - Q D without pivoting on the top block, in place on M2: below the diagonal -> L (= V's top block), on and above -> the
+    // eliminated entries q~ of Q with U[i][j] = -D_j q~[i][j] (i < j), U[j][j] = piv_j = 1 + |q~_jj|
+    for (int j = 0; j < B; j++) {
+        const double qjj = M2[j * P65 + j];
+        const double dj = (qjj >= 0.0) ? -1.0 : 1.0, pv = 1.0 - dj * qjj;
+        __syncthreads();
+        if (tid == 0) { Dg[j] = dj; piv[j] = pv; }
+        if (tid < B && tid > j) M2[tid * P65 + j] = -dj * M2[tid * P65 + j] / pv;
+        __syncthreads();
+        if (i > j) {
+            const double lij = M2[i * P65 + j];
+#pragma unroll 4
+            for (int c = j0; c < j0 + 16; c++)
+                if (c > j) M2[i * P65 + c] -= lij * M2[j * P65 + c];
+        }
+        __syncthreads();
+    }
+    // Rs = D (R2 R1): the band block below the diagonal block of this panel (upper triangular)
+    mm64([&](int a, int k) { return M0[a * P65 + k]; }, [&](int k, int b) { return M3[k * P65 + b]; },
+         [&](int a, int b, double v) { if (b >= a) Aband[(long long)a * lda + b] = Dg[a] * v; }, tid);
+    __syncthreads();
+    // T = U Y1^-T: T Y1' = U, Y1' unit upper triangular with Y1'[k][j] = L[j][k]                     -> M0
+    solve_right_upper64(M0, [&](int k, int j) { return M2[j * P65 + k]; }, [&](int) { return 1.0; },
+                        [&](int a, int b) { return (a == b) ? piv[b] : ((a < b) ? -Dg[b] * M2[a * P65 + b] : 0.0); }, tid);
+    // Xm U = -R2^-1 D                                                                              -> M3
+    solve_right_upper64(M3, [&](int k, int j) { return -Dg[j] * M2[k * P65 + j]; }, [&](int j) { return piv[j]; },
+                        [&](int a, int b) { return -M1[a * P65 + b] * Dg[b]; }, tid);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int c = j0 + q;
+        Tout[i * B + c] = M0[i * P65 + c];
+        Xm[i * B + c] = M3[i * P65 + c];
+        const double v = (i == c) ? 1.0 : ((i > c) ? M2[i * P65 + c] : 0.0);
+        VW[(long long)i * (2 * B) + c] = v;
+        Vst[(long long)i * ldv + c] = v;
+    }
+}
+
+// ---- last panel: m <= 64 rows, plain Householder QR in LDS ------------------------------------------------------------------
+// P: the m x 64 block (ld lda), overwritten by R (upper trapezoidal; below the diagonal zeros).  V -> VW / Vst, T -> Tout.
+__global__ __launch_bounds__(256) void small_qr_kernel(int m, double *P, long long lda, double *VW, double *Vst, long long ldv, double *Tout)
+{
+    extern __shared__ double lds[];
+    double *A = lds, *V = lds + MAT, *Gm = lds + 2 * MAT, *Tm = lds + 3 * MAT;
+    __shared__ double vcol[B], wrow[B], tau[B], sc[2];
+    const int tid = threadIdx.x, i = tid >> 2, j0 = (tid & 3) * 16;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        A[i * P65 + j0 + q] = (i < m) ? P[(long long)i * lda + j0 + q] : 0.0;
+        V[i * P65 + j0 + q] = 0.0;
+        Tm[i * P65 + j0 + q] = 0.0;
+    }
+    if (tid < B) tau[tid] = 0.0;
+    __syncthreads();
+    const int nref = (m - 1 < B) ? m - 1 : B;
+    for (int j = 0; j < nref; j++) {
+        if (tid < 64) {                                   // wave 0: reflector of column j, rows j .. m-1
+            const double x = (tid >= j && tid < m) ? A[tid * P65 + j] : 0.0;
+            const double alpha = __shfl(x, j, 64);
+            const double xn2 = wave_sum64((tid > j) ? x * x : 0.0);
+            double beta = alpha, t = 0.0, scal = 0.0;
+            if (xn2 != 0.0) { beta = -copysign(sqrt(alpha * alpha + xn2), alpha); t = (beta - alpha) / beta; scal = 1.0 / (alpha - beta); }
+            const double v = (tid == j) ? 1.0 : ((tid > j && tid < m) ? x * scal : 0.0);
+            vcol[tid] = v;
+            V[tid * P65 + j] = v;
+            if (tid == 0) { tau[j] = t; sc[0] = t; sc[1] = beta; }
+        }
+        __syncthreads();
+        if (tid < B) {                                    // w_c = v' A[:, c] for c > j
+            double s = 0.0;
+            if (tid > j) for (int r = j; r < m; r++) s = fma(vcol[r], A[r * P65 + tid], s);
+            wrow[tid] = s;
+        }
+        __syncthreads();
+        const double t = sc[0];
+#pragma unroll 4
+        for (int c = j0; c < j0 + 16; c++) {
+            if (c > j && i >= j) A[i * P65 + c] -= t * vcol[i] * wrow[c];
+            else if (c == j && i >= j) A[i * P65 + c] = (i == j) ? sc[1] : 0.0;
+        }
+        __syncthreads();
+    }
+    // Gram of V and the dlarft recurrence (forward, columnwise)
+    mm64([&](int a, int k) { return V[k * P65 + a]; }, [&](int k, int b) { return V[k * P65 + b]; },
+         [&](int a, int b, double v) { Gm[a * P65 + b] = v; }, tid);
+    __syncthreads();
+    for (int j = 0; j < B; j++) {
+        const double tj = tau[j];
+        double v = 0.0;
+        if (tid < j) {
+            for (int l = tid; l < j; l++) v = fma(Tm[tid * P65 + l], Gm[l * P65 + j], v);
+            v *= -tj;
+        }
+        __syncthreads();
+        if (tid < j) Tm[tid * P65 + j] = v;
+        if (tid == j) Tm[j * P65 + j] = tj;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int c = j0 + q;
+        Tout[i * B + c] = Tm[i * P65 + c];
+        if (i < m) {
+            P[(long long)i * lda + c] = A[i * P65 + c];
+            VW[(long long)i * (2 * B) + c] = V[i * P65 + c];
+            Vst[(long long)i * ldv + c] = V[i * P65 + c];
+        }
+    }
+}
+
+// rows [r_begin, m) of the panel's V (VW columns 0..63) into the reflector store
+__global__ void copy_v_kernel(long long m, long long r_begin, const double *VW, double *Vst, long long ldv)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long r = r_begin + idx / B, c = idx % B;
+    if (r < m) Vst[r * ldv + c] = VW[r * (2 * B) + c];
+}
+
+// =================================================================================================================================
+size_t sb2_bytes(int n)
+{
+    const size_t nn = (size_t)n * n;
+    const size_t ng = ((size_t)n + SB_G - 1) / SB_G + 1, kmax = ((size_t)n + B - 1) / B + 1;
+    return 8 * (2 * nn + (size_t)n * 4 * B + (size_t)n * SB_LD + (size_t)n * (kmax + 1) + 2 * ng * kmax * 128 * SB_G + (kmax + 1) * SB_G * n +
+                (ng + 1) * B * B + 2 * (size_t)BT1_BLOCK * BT1_BLOCK + 2 * (size_t)BT1_BLOCK * n + 64 * B * B) + 4 * ((size_t)n + 64);
+}
+
+static int alloc_d2(double **p, size_t count)
+{
+    hipError_t e = hipMalloc(p, (count ? count : 1) * sizeof(double));
+    if (e != hipSuccess) { set_error("hipMalloc(%zu doubles) failed: %s", count, hipGetErrorString(e)); *p = nullptr; return PG_ENOMEM; }
+    return PG_OK;
+}
+
+int sb2_alloc(int n, Sb2Work &w)
+{
+    w = Sb2Work{};
+    w.n = n;
+    w.npan = 0;
+    for (int j = 0; n - j - B >= 2; j += B) w.npan++;
+    w.nk = (n + B - 1) / B + 1;
+    w.ng = (std::max(n - 2, 1) + SB_G - 1) / SB_G;
+    w.kmax = (n + B - 1) / B + 1;
+    const size_t nn = (size_t)n * n;
+    int rc = PG_OK;
+    struct { double **p; size_t cnt; } req[] = {
+        {&w.Vst, nn}, {&w.Tst, (size_t)(w.npan + 1) * B * B}, {&w.VW, ((size_t)n + 128) * 2 * B}, {&w.Qb, ((size_t)n + 128) * B}, {&w.sm, (size_t)16 * B * B},
+        {&w.S, ((size_t)n + 2) * SB_LD}, {&w.VV, nn}, {&w.TAU, (size_t)n * w.nk}, {&w.Vp, (size_t)w.ng * w.kmax * 128 * SB_G},
+        {&w.Vtp, (size_t)w.ng * w.kmax * 128 * SB_G}, {&w.Wws, ((size_t)w.kmax + 1) * SB_G * n}, {&w.G, (size_t)BT1_BLOCK * BT1_BLOCK},
+        {&w.T, (size_t)BT1_BLOCK * BT1_BLOCK}, {&w.W, (size_t)BT1_BLOCK * n}, {&w.W2, (size_t)BT1_BLOCK * n}};
+    for (auto &r : req) { if (!rc) rc = alloc_d2(r.p, r.cnt); }
+    if (!rc && hipMalloc(&w.prog, ((size_t)n + 16) * sizeof(int)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
+    if (!rc && hipMalloc(&w.fail, 4 * sizeof(int)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
+    if (rc) sb2_free(w);
+    return rc;
+}
+
+void sb2_free(Sb2Work &w)
+{
+    for (double *p : {w.Vst, w.Tst, w.VW, w.Qb, w.sm, w.S, w.VV, w.TAU, w.Vp, w.Vtp, w.Wws, w.G, w.T, w.W, w.W2}) if (p) (void)hipFree(p);
+    if (w.prog) (void)hipFree(w.prog);
+    if (w.fail) (void)hipFree(w.fail);
+    w = Sb2Work{};
+}
+
+// ---- stage 1 ------------------------------------------------------------------------------------------------------------------
+int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
+{
+    hipStream_t st = ctx->stream;
+    constexpr int LDS4 = 4 * MAT * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recon_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAT * 8));
+        attr_done = true;
+    }
+    PG_HIP(hipMemsetAsync(w.Vst, 0, (size_t)n * n * 8, st));
+    PG_HIP(hipMemsetAsync(w.Tst, 0, (size_t)(w.npan + 1) * B * B * 8, st));
+    PG_HIP(hipMemsetAsync(w.fail, 0, 4 * sizeof(int), st));
+    double *sm = w.sm;
+    auto SM = [&](int k) { return sm + (size_t)k * B * B; };
+    const long long ld = n;
+    int pan = 0;
+    for (int j = 0; n - j - B >= 2; j += B, pan++) {
+        const long long m = n - j - B;
+        double *P = A + (size_t)(j + B) * ld + j;                 // m x 64 panel below the diagonal block
+        double *Vs = w.Vst + (size_t)(j + B) * ld + j;
+        double *Tp = w.Tst + (size_t)pan * B * B;
+        int rc = PG_OK;
+        if (m > B) {
+            // CholeskyQR2: G1 = P'P, R1; Q1 = P R1^-1; G2 = Q1'Q1, R2; (Q = Q1 R2^-1 only through its top block and Xm)
+            rc = dgemm(ctx, true, B, B, m, 1.0, P, ld, P, ld, 0.0, SM(SM_G1), B);
+            if (rc) return rc;
+            chol_inv_kernel<<<1, 256, 2 * MAT * 8, st>>>(SM(SM_G1), SM(SM_R1), SM(SM_R1INV), w.fail);
+            rc = dgemm(ctx, false, m, B, B, 1.0, P, ld, SM(SM_R1INV), B, 0.0, w.Qb, B);
+            if (!rc) rc = dgemm(ctx, true, B, B, m, 1.0, w.Qb, B, w.Qb, B, 0.0, SM(SM_G2), B);
+            if (rc) return rc;
+            recon_kernel<<<1, 256, LDS4, st>>>(SM(SM_G2), SM(SM_R1), w.Qb, P, ld, w.VW, Vs, ld, Tp, SM(SM_XM), w.fail);
+            // rows 64.. of V = Q1[64:, :] Xm  -> VW[:, 0:64]
+            rc = dgemm(ctx, false, m - B, B, B, 1.0, w.Qb + (size_t)B * B, B, SM(SM_XM), B, 0.0, w.VW + (size_t)B * 2 * B, 2 * B);
+            if (rc) return rc;
+            copy_v_kernel<<<(unsigned)(((m - B) * B + 255) / 256), 256, 0, st>>>(m, B, w.VW, Vs, ld);
+        } else {
+            small_qr_kernel<<<1, 256, LDS4, st>>>((int)m, P, ld, w.VW, Vs, ld, Tp);
+        }
+        PG_HIP(hipGetLastError());
+        // two-sided update of A22 = A[j+64:, j+64:] (m x m):  Y = A22 V T,  W = Y - 1/2 V (T' (V' Y)),  A22 -= V W' + W V'
+        double *A22 = A + (size_t)(j + B) * ld + (j + B);
+        double *V = w.VW, *Wc = w.VW + B;                         // columns 0..63 / 64..127 of VW (ld 128)
+        rc = dgemm(ctx, false, m, B, m, 1.0, A22, ld, V, 2 * B, 0.0, w.Qb, B);                      // X  = A22 V
+        if (!rc) rc = dgemm(ctx, false, m, B, B, 1.0, w.Qb, B, Tp, B, 0.0, Wc, 2 * B);              // Y  = X T           -> W columns
+        if (!rc) rc = dgemm(ctx, true, B, B, m, 1.0, V, 2 * B, Wc, 2 * B, 0.0, SM(SM_M1), B);       // M1 = V' Y
+        if (!rc) rc = dgemm(ctx, true, B, B, B, -0.5, Tp, B, SM(SM_M1), B, 0.0, SM(SM_M2), B);      // M2 = -1/2 T' M1
+        if (!rc) rc = dgemm(ctx, false, m, B, B, 1.0, V, 2 * B, SM(SM_M2), B, 1.0, Wc, 2 * B);      // W  = Y + V M2
+        if (rc) return rc;
+        DgemmDesc d;                                                                               // A22 -= [V W] [W V]'
+        d.transB = true; d.kxorB = B; d.M = m; d.N = m; d.K = 2 * B; d.alpha = -1.0; d.beta = 1.0;
+        d.A = w.VW; d.lda = 2 * B; d.B = w.VW; d.ldb = 2 * B; d.C = A22; d.ldc = ld;
+        rc = dgemm_ex(ctx, d);
+        if (rc) return rc;
+    }
+    return PG_OK;
+}
+
+// ---- band storage ---------------------------------------------------------------------------------------------------------------
+// S[i][o], o = j - i + (SB_LD - 1) for j <= i, i - j < SB_LD: the band (i - j <= b) from A, zeros in the room for the bulge
+__global__ void band_extract_kernel(int n, const double *A, double *S)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)(n + 2) * SB_LD) return;
+    const int i = (int)(idx / SB_LD), o = (int)(idx % SB_LD);
+    const int j = i - (SB_LD - 1) + o;
+    S[idx] = (i < n && j >= 0 && i - j <= B) ? A[(size_t)i * n + j] : 0.0;
+}
+__global__ void band_de_kernel(int n, const double *S, double *d, double *e)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = S[(size_t)i * SB_LD + SB_LD - 1];
+    if (i + 1 < n) e[i] = S[(size_t)(i + 1) * SB_LD + SB_LD - 2];
+}
+
+// ---- stage 2: bulge chasing -------------------------------------------------------------------------------------------------------
+// agent-scope relaxed accesses: global_load/store ... sc1 (write-through stores; loads served by L2, never by this CU's L1)
+__device__ __forceinline__ double ld_sc1(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr int BC_DONE = INT_MAX / 2;
+// debugging aid (pgx_sb2_set_debug): a host-mapped int array the bulge-chasing kernel leaves its position in (sweep, step, phase)
+static int *g_bc_debug = nullptr;
+void sb2_set_debug(int *p) { g_bc_debug = p; }
+#ifndef PG_BC_DEBUG
+#define BC_HB(ph) do { } while (0)
+#else
+#define BC_HB(ph) do { if (dbg && tid == 0) { __hip_atomic_store(&dbg[0], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+    __hip_atomic_store(&dbg[1], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&dbg[2], ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } } while (0)
+#endif
+
+// prog[s] = number of completed steps of sweep s (BC_DONE when the sweep has ended); ctl[1] = abort flag.
+__global__ __launch_bounds__(256) void bc_kernel(int n, double *S, double *VV, double *TAU, int nk, int *prog, int *ctl, int *fail, int *dbg)
+{
+    // 72 KB of LDS: dynamic, with the launch attribute raised — a STATIC allocation above 64 KB compiles but is not honoured at launch
+    // (accesses beyond 64 KB read 0 and drop writes: the sweep index kept there never advanced; first GPU run of this kernel)
+    extern __shared__ double bc_lds[];
+    double *E = bc_lds, *D = bc_lds + MAT;
+    double *vcur = D + MAT, *vprev = vcur + B, *wv = vprev + B, *qv = wv + B;
+    double (*part)[B] = reinterpret_cast<double (*)[B]>(qv + B);
+    double (*part2)[B] = part + 4;
+    double *sc = reinterpret_cast<double *>(part2 + 4);
+    const int tid = threadIdx.x, lane = tid & 63, q4 = tid >> 6;     // (lane, q4): one of 64 columns/rows x a quarter of the other index
+    const int ri = tid >> 2, c0 = (tid & 3) * 16;                    // (ri, c0): row ri, 16 consecutive columns from c0
+    // Sweeps are dealt round-robin: workgroup w takes sweeps w, w + G, w + 2G, ... in order, so the sweep a workgroup waits for
+    // always belongs to its left neighbour, which is resident (the grid never exceeds one workgroup per CU of an otherwise idle
+    // stream).  (A dynamic queue — lane 0 fetching the next sweep with an atomic, broadcast through LDS — was the first version:
+    // the compiler rotated that `if (tid == 0)` region into the loop latch and sent the other 63 lanes of wave 0 into the next
+    // iteration's barriers ahead of lane 0; the kernel re-ran sweep 0 for ever.  A scalar loop counter cannot diverge.)
+    for (int s = blockIdx.x; s <= n - 3; s += gridDim.x) {
+        double taup = 0.0;
+        for (int k = 0;; k++) {
+            const int r0 = s + 1 + k * B;
+            if (r0 >= n) break;
+            const int L = (n - r0 < B) ? n - r0 : B;
+            BC_HB(1);
+            if (s > 0) {
+                // step (s, k) reads rows r0 .. r0 + 63: the last of them is the first row of step (s - 1, k + 1)
+                if (tid == 0) {
+                    int spins = 0;
+                    while (__hip_atomic_load(&prog[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k + 2) {
+                        if (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        if (++spins > (1 << 20)) {            // never expected: the sweep ahead is always running; do not hang the GPU
+                            __hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (atomicOr(&fail[1], 1) == 0) { fail[2] = s; fail[3] = k; }
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                __syncthreads();
+            }
+            BC_HB(2);
+            // ---- load: E = rows r0.., columns r0-64 .. r0-1 (k >= 1);  D = rows/columns r0.. (lower triangle, mirrored)
+            {
+                const bool rok = ri < L;
+                const double *row = S + (size_t)(r0 + ri) * SB_LD;
+                if (k >= 1) {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const int c = c0 + q;
+                        E[ri * P65 + c] = rok ? ld_sc1(row + (B - 1) + c - ri) : 0.0;       // o = (r0-64+c) - (r0+ri) + 127
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int c = c0 + q;
+                    if (c <= ri) {
+                        const double v = rok ? ld_sc1(row + (SB_LD - 1) + c - ri) : 0.0;   // o = c - ri + 127
+                        D[ri * P65 + c] = v;
+                        D[c * P65 + ri] = v;
+                    }
+                }
+            }
+            double x0 = 0.0;
+            if (k == 0 && tid < B) x0 = (tid < L) ? ld_sc1(S + (size_t)(r0 + tid) * SB_LD + (SB_LD - 2) - tid) : 0.0;   // (r0 + i, s): o = 126 - i
+            __syncthreads();
+            BC_HB(3);
+            // ---- (1) right-apply the previous reflector to E: u = E vprev;  E -= taup u vprev'
+            if (k >= 1) {
+                double s_ = 0.0;
+#pragma unroll
+                for (int c = 16 * q4; c < 16 * q4 + 16; c++) s_ = fma(E[lane * P65 + c], vprev[c], s_);
+                part[q4][lane] = s_;
+                __syncthreads();
+                const double tu = taup * (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
+#pragma unroll
+                for (int c = 16 * q4; c < 16 * q4 + 16; c++) E[lane * P65 + c] = fma(-tu, vprev[c], E[lane * P65 + c]);
+                if (q4 == 0) x0 = E[lane * P65];       // first column, updated by this thread itself
+            }
+            // ---- (2) reflector (wave 0)
+            if (q4 == 0) {
+                const double alpha = __shfl(x0, 0, 64);
+                const double xn2 = wave_sum64((lane >= 1) ? x0 * x0 : 0.0);
+                double beta = alpha, tau = 0.0, scal = 0.0;
+                if (xn2 != 0.0) { beta = -copysign(sqrt(alpha * alpha + xn2), alpha); tau = (beta - alpha) / beta; scal = 1.0 / (alpha - beta); }
+                const double v = (lane == 0) ? 1.0 : x0 * scal;     // rows >= L carry x0 = 0
+                vcur[lane] = v;
+                if (lane == 0) { sc[0] = tau; sc[1] = beta; TAU[(size_t)s * nk + k] = tau; }
+                if (lane < L) VV[(size_t)s * n + r0 + lane] = v;
+                if (k >= 1) E[lane * P65] = (lane == 0) ? beta : 0.0;
+                else if (lane < L) st_sc1(S + (size_t)(r0 + lane) * SB_LD + (SB_LD - 2) - lane, (lane == 0) ? beta : 0.0);
+            }
+            __syncthreads();
+            BC_HB(4);
+            const double tau = sc[0];
+            // ---- (3a), (4a) column products with the new reflector: w = E'v, p = D v
+            {
+                double sw = 0.0, sp = 0.0;
+#pragma unroll
+                for (int r = 16 * q4; r < 16 * q4 + 16; r++) {
+                    const double vr = vcur[r];
+                    sp = fma(D[r * P65 + lane], vr, sp);
+                    if (k >= 1) sw = fma(E[r * P65 + lane], vr, sw);
+                }
+                part[q4][lane] = sw;
+                part2[q4][lane] = sp;
+            }
+            __syncthreads();
+            if (q4 == 0) wv[lane] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+            if (q4 == 1) {
+                const double p = tau * (((part2[0][lane] + part2[1][lane]) + part2[2][lane]) + part2[3][lane]);
+                const double pv = wave_sum64(p * vcur[lane]);
+                qv[lane] = p - 0.5 * tau * pv * vcur[lane];
+            }
+            __syncthreads();
+            BC_HB(5);
+            // ---- (3b), (4b) rank updates, written straight to the band (write-through)
+            if (ri < L) {
+                double *row = S + (size_t)(r0 + ri) * SB_LD;
+                const double vi = vcur[ri], qi = qv[ri], tvi = tau * vi;
+                if (k >= 1) {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const int c = c0 + q;
+                        const double e = E[ri * P65 + c];
+                        st_sc1(row + (B - 1) + c - ri, (c == 0) ? e : fma(-tvi, wv[c], e));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int c = c0 + q;
+                    if (c <= ri) st_sc1(row + (SB_LD - 1) + c - ri, D[ri * P65 + c] - (vi * qv[c] + qi * vcur[c]));
+                }
+            }
+            if (tid < B) vprev[tid] = vcur[tid];
+            taup = tau;
+            // every storing wave drains its stores, the workgroup meets, then one lane publishes the step
+            BC_HB(6);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            BC_HB(7);
+            if (tid == 0) __hip_atomic_store(&prog[s], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) __hip_atomic_store(&prog[s], BC_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2Work &w)
+{
+    hipStream_t st = ctx->stream;
+    band_extract_kernel<<<(unsigned)(((size_t)(n + 2) * SB_LD + 255) / 256), 256, 0, st>>>(n, A, w.S);
+    PG_HIP(hipMemsetAsync(w.prog, 0, ((size_t)n + 16) * sizeof(int), st));
+    PG_HIP(hipMemsetAsync(w.VV, 0, (size_t)n * n * 8, st));
+    PG_HIP(hipMemsetAsync(w.TAU, 0, (size_t)n * w.nk * 8, st));
+    if (n >= 3) {
+        // a sweep trails the one ahead by two blocks: n / 128 sweeps are in flight at most; workgroups beyond that would only poll
+        int nwg = n / (2 * B) + 4;
+        nwg = std::max(1, std::min(nwg, std::min(ctx->num_cu, 256)));
+        if (const char *e_ = getenv("PG_BC_NWG")) nwg = std::max(1, std::min(atoi(e_), 256));     // A/B and debugging
+        constexpr int BC_LDS = (2 * MAT + 4 * B + 8 * B + 2) * 8;
+        static bool attr_done = false;
+        if (!attr_done) {
+            PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS));
+            attr_done = true;
+        }
+        bc_kernel<<<nwg, 256, BC_LDS, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.prog, w.prog + n, w.fail, g_bc_debug);
+    }
+    band_de_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, w.S, d, e);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+// ---- back-transformation with the stage-2 reflectors ----------------------------------------------------------------------------
+// Block (G, k): sweeps s0 = G g .. s0 + g - 1 at block index k act on rows row0 = s0 + 1 + k b .. row0 + b + g - 2.  Column i of V
+// (sweep s0 + i) occupies rows i .. i + b - 1 of the block.  One workgroup builds V (128 x 64, zero padded), its compact-WY factor
+// T (forward, columnwise: H_{s0} H_{s0+1} ... = I - V T V') and V T.
+__global__ __launch_bounds__(256) void bt2_prep_kernel(int n, int nk, int ng, const double *VV, const double *TAU, double *Vp, double *Vtp)
+{
+    extern __shared__ double lds[];
+    constexpr int VR = 128;
+    double *V = lds;                    // [128][65]
+    double *Gm = lds + VR * P65;        // [64][65]
+    double *Tm = Gm + MAT;              // [64][65]
+    __shared__ double tau[SB_G];
+    const int G = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+    const int s0 = G * SB_G, row0 = s0 + 1 + k * B;
+    if (row0 >= n) return;
+    const size_t blk = ((size_t)k * ng + G) * VR * SB_G;
+    // V[r][i] = VV[s0 + i][row0 + r] for i <= r < i + 64, sweep and row in range
+    for (int idx = tid; idx < VR * SB_G; idx += 256) {
+        const int r = idx & 127, i = idx >> 7;       // consecutive threads walk along a sweep's row of VV
+        const int s = s0 + i;
+        double v = 0.0;
+        if (s <= n - 3 && r >= i && r < i + B && row0 + r < n) v = VV[(size_t)s * n + row0 + r];
+        V[r * P65 + i] = v;
+    }
+    if (tid < SB_G) {
+        const int s = s0 + tid;
+        tau[tid] = (s <= n - 3 && s + 1 + k * B < n) ? TAU[(size_t)s * nk + k] : 0.0;
+        for (int j = 0; j < SB_G; j++) Tm[tid * P65 + j] = 0.0;
+    }
+    __syncthreads();
+    {   // Gram (upper part is what the recurrence reads)
+        const int i = tid >> 2, j0 = (tid & 3) * 16;
+        double acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[q] = 0.0;
+        for (int r = 0; r < VR; r++) {
+            const double a = V[r * P65 + i];
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = fma(a, V[r * P65 + j0 + q], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) Gm[i * P65 + j0 + q] = acc[q];
+    }
+    __syncthreads();
+    for (int j = 0; j < SB_G; j++) {
+        const double tj = tau[j];
+        double v = 0.0;
+        if (tid < j) {
+            for (int l = tid; l < j; l++) v = fma(Tm[tid * P65 + l], Gm[l * P65 + j], v);
+            v *= -tj;
+        }
+        __syncthreads();
+        if (tid < j) Tm[tid * P65 + j] = v;
+        if (tid == j) Tm[j * P65 + j] = tj;
+        __syncthreads();
+    }
+    // V and V T out (row-major 128 x 64)
+    for (int idx = tid; idx < VR * SB_G; idx += 256) {
+        const int r = idx >> 6, j = idx & 63;
+        double s = 0.0;
+        for (int l = 0; l <= j; l++) s = fma(V[r * P65 + l], Tm[l * P65 + j], s);
+        Vp[blk + idx] = V[r * P65 + j];
+        Vtp[blk + idx] = s;
+    }
+}
+
+int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w)
+{
+    if (n < 3) return PG_OK;
+    hipStream_t st = ctx->stream;
+    constexpr int VR = 128, HGT = B + SB_G - 1;      // rows of a block
+    const int ng = w.ng, kmax = w.kmax;
+    const size_t lds = (size_t)(VR * P65 + 2 * MAT) * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    bt2_prep_kernel<<<dim3(ng, kmax), 256, lds, st>>>(n, w.nk, ng, w.VV, w.TAU, w.Vp, w.Vtp);
+    PG_HIP(hipGetLastError());
+    const size_t blk = (size_t)VR * SB_G;
+    const int glast = ng - 1;
+    // wavefront t: blocks (G, k) with (glast - G) + k = t; their rows start (g + b) apart
+    for (int t = 0;; t++) {
+        const int kmin = std::max(0, t - glast);
+        const long long base = (long long)SB_G * (glast - t) + 1;          // row0(k) = base + k (g + b)
+        // largest k with G = glast - t + k <= glast (k <= t) and row0 < n
+        long long kmx = t;
+        if (base + kmx * (SB_G + B) >= n) kmx = (n - 1 - base) / (SB_G + B);   // floor; base may be negative only when kmin > 0
+        if (n - 1 - base < 0) kmx = -1;
+        if (kmx < kmin) break;     // wavefronts are non-empty up to the last one (t <= glast: k = 0 exists; beyond: once empty, always empty)
+        const int nb = (int)(kmx - kmin + 1);
+        const long long row_first = base + (long long)kmin * (SB_G + B), row_last = base + kmx * (SB_G + B);
+        const long long h_last = std::min<long long>(HGT, n - row_last);
+        const int G0 = glast - t + kmin;
+        DgemmDesc d1;                               // W_z = V_z' Z[rows_z, :]
+        d1.transA = true; d1.M = SB_G; d1.N = n; d1.K = HGT; d1.alpha = 1.0; d1.beta = 0.0;
+        d1.A = w.Vp + ((size_t)kmin * ng + G0) * blk; d1.lda = SB_G; d1.strideA = (long long)(ng + 1) * blk;
+        d1.B = Z + (size_t)row_first * n; d1.ldb = n; d1.strideB = (long long)(SB_G + B) * n;
+        d1.C = w.Wws; d1.ldc = n; d1.strideC = (long long)SB_G * n;
+        d1.nbatch = nb; d1.K_last = h_last; d1.allow_splitk = false;
+        int rc = dgemm_ex(ctx, d1);
+        if (rc) return rc;
+        DgemmDesc d2;                               // Z[rows_z, :] -= (V T)_z W_z
+        d2.M = HGT; d2.N = n; d2.K = SB_G; d2.alpha = -1.0; d2.beta = 1.0;
+        d2.A = w.Vtp + ((size_t)kmin * ng + G0) * blk; d2.lda = SB_G; d2.strideA = (long long)(ng + 1) * blk;
+        d2.B = w.Wws; d2.ldb = n; d2.strideB = (long long)SB_G * n;
+        d2.C = Z + (size_t)row_first * n; d2.ldc = n; d2.strideC = (long long)(SB_G + B) * n;
+        d2.nbatch = nb; d2.M_last = h_last; d2.allow_splitk = false;
+        rc = dgemm_ex(ctx, d2);
+        if (rc) return rc;
+    }
+    return PG_OK;
+}
+
+// ---- back-transformation with the stage-1 reflectors ----------------------------------------------------------------------------
+__global__ void bt1_diag_t_kernel(int m, int pan0, const double *Tst, double *T)
+{
+    // diagonal 64 x 64 blocks of the aggregated T (ld BT1_BLOCK) = the panels' own factors
+    const int sub = blockIdx.x, tid = threadIdx.x;
+    if (sub * B >= m) return;
+    const double *src = Tst + (size_t)(pan0 + sub) * B * B;
+    for (int idx = tid; idx < B * B; idx += blockDim.x) {
+        const int i = idx / B, j = idx % B;
+        T[(size_t)(sub * B + i) * BT1_BLOCK + sub * B + j] = src[idx];
+    }
+}
+
+int bt1_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w)
+{
+    hipStream_t s = ctx->stream;
+    const int nref = w.npan * B;                      // reflector columns 0 .. nref-1; column i has its unit at row i + 64
+    if (nref == 0) return PG_OK;
+    constexpr int BB = BT1_BLOCK;
+    const int nblk = (nref + BB - 1) / BB;
+    for (int b = nblk - 1; b >= 0; b--) {
+        const int i0 = b * BB, m = std::min(BB, nref - i0), nsub = (m + B - 1) / B;
+        const long long rows = n - i0 - B;
+        if (rows <= 0) continue;
+        const double *V = w.Vst + (size_t)(i0 + B) * n + i0;      // rows i0 + 64 .., columns i0 .. i0 + m - 1
+        double *Zr = Z + (size_t)(i0 + B) * n;
+        int rc = dgemm(ctx, true, m, m, rows, 1.0, V, n, V, n, 0.0, w.G, BB);
+        if (rc) return rc;
+        PG_HIP(hipMemsetAsync(w.T, 0, (size_t)BB * BB * sizeof(double), s));
+        bt1_diag_t_kernel<<<nsub, 256, 0, s>>>(m, i0 / B, w.Tst, w.T);
+        PG_HIP(hipGetLastError());
+        for (int k = 1; k < nsub; k++) {     // block column k of T: T(0:r, r:r+w) = -T(0:r,0:r) G(0:r, r:r+w) T(r:r+w, r:r+w); W is free here
+            const int r = k * B, wdt = std::min(B, m - r);
+            rc = dgemm(ctx, false, r, wdt, r, 1.0, w.T, BB, w.G + r, BB, 0.0, w.W, B);
+            if (!rc) rc = dgemm(ctx, false, r, wdt, wdt, -1.0, w.W, B, w.T + (size_t)r * BB + r, BB, 0.0, w.T + r, BB);
+            if (rc) return rc;
+        }
+        rc = dgemm(ctx, true, m, n, rows, 1.0, V, n, Zr, n, 0.0, w.W, n);          // W  = V' Z
+        if (!rc) rc = dgemm(ctx, false, m, n, m, 1.0, w.T, BB, w.W, n, 0.0, w.W2, n);   // W2 = T W
+        if (!rc) rc = dgemm(ctx, false, rows, n, m, -1.0, V, n, w.W2, n, 1.0, Zr, n);   // Z -= V W2
+        if (rc) return rc;
+    }
+    return PG_OK;
+}
+
+}  // namespace pg

@@ -13,6 +13,7 @@
 // reference's float32 LAPACK (SURVEY 8c Tier B).
 #include "common.hpp"
 #include "dgemm.hpp"
+#include "sb2.hpp"
 
 #include <atomic>
 #include <chrono>
@@ -1027,12 +1028,8 @@ static int backtransform_device(pg_ctx *ctx, int n, const double *Vall, const do
     return PG_OK;
 }
 
-extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *evals, float *U, double *evals64, double *U64)
+static int syevd_onestage(pg_ctx *ctx, int n0, const float *K, float *evals, float *U, double *evals64, double *U64)
 {
-    PG_REQUIRE(ctx && K && (evals || evals64), "pg_syevd_dev: NULL argument");
-    PG_REQUIRE(n64 >= 1 && n64 <= 65535, "pg_syevd_dev: n=%lld out of range", (long long)n64);
-    PG_HIP(hipSetDevice(ctx->device));
-    const int n0 = (int)n64;
     // Odd n: work on N = n + 1 with a zero extra row/column.  It stays exactly decoupled through the reduction (v and w
     // have a zero there), its diagonal entry of T is then set above every other eigenvalue, so it comes out last with
     // eigenvector e_N and is dropped — and the even-n symmetric symv (half the HBM bytes, 16-byte loads) serves every n.
@@ -1121,3 +1118,143 @@ extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *eva
     mark("free");
     return rc;
 }
+
+// ---- two-stage path (csrc/sb2.hip): dense -> band (GEMM-bound) -> tridiagonal (bulge chasing) -> divide & conquer -> Q1 (Q2 Z) ----
+constexpr int PG_RETRY_ONESTAGE = 1000;    // internal: a panel of the band reduction could not be factored by CholeskyQR2
+static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, float *U, double *evals64, double *U64)
+{
+    hipStream_t st = ctx->stream;
+    const bool timing = getenv("PG_SYEVD_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        const double t = now();
+        fprintf(stderr, "[pg_syevd_dev 2-stage n=%d] %-16s %8.1f ms\n", n, what, (t - t_prev) * 1e3);
+        t_prev = t;
+    };
+    Sb2Work sw;
+    StedcWork wk;
+    double *A = nullptr, *dd = nullptr, *de = nullptr, *dev_ev = nullptr;
+    int rc = PG_OK;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(st);
+        for (double *p : {A, dd, de, dev_ev}) if (p) (void)hipFree(p);
+        sb2_free(sw);
+        stedc_free(wk);
+    };
+    rc = alloc_d(&A, (size_t)n * n);
+    if (!rc) rc = alloc_d(&dd, (size_t)n);
+    if (!rc) rc = alloc_d(&de, (size_t)n);
+    if (!rc) rc = alloc_d(&dev_ev, (size_t)n);
+    if (!rc) rc = sb2_alloc(n, sw);
+    if (!rc) rc = stedc_alloc(n, wk);
+    if (rc) { cleanup(); return rc; }
+    mark("allocate");
+    sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n, n, K, A);
+    rc = sy2sb_device(ctx, n, A, sw);
+    mark("dense->band");
+    if (!rc) rc = sb2st_device(ctx, n, A, dd, de, sw);
+    std::vector<double> hd(n), he(n, 0.0), ev;
+    int hfail[4] = {0, 0, 0, 0};
+    if (!rc) {
+        if (hipMemcpyAsync(hd.data(), dd, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(he.data(), de, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(hfail, sw.fail, sizeof(hfail), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { set_error("pg_syevd_dev: reading T back failed: %s", hipGetErrorString(hipGetLastError())); rc = PG_EHIP; }
+    }
+    mark("band->tridiag");
+    if (!rc && (hfail[0] || hfail[1])) {
+        if (timing) fprintf(stderr, "[pg_syevd_dev 2-stage n=%d] flags %d %d: falling back to the one-stage reduction\n", n, hfail[0], hfail[1]);
+        cleanup();
+        return PG_RETRY_ONESTAGE;
+    }
+    double *Z = nullptr;
+    if (!rc) rc = stedc_device(ctx, n, hd.data(), he.data(), ev, wk, &Z);
+    mark("divide&conquer");
+    if (!rc) rc = bt2_device(ctx, n, Z, sw);
+    mark("back-transform 2");
+    if (!rc) rc = bt1_device(ctx, n, Z, sw);
+    mark("back-transform 1");
+    if (!rc) {
+        hipError_t e1 = hipMemcpyAsync(dev_ev, ev.data(), (size_t)n * 8, hipMemcpyHostToDevice, st);
+        if (e1 != hipSuccess) rc = PG_EHIP;
+        if (!rc) {
+            finalize_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n, n, Z, dev_ev, U, evals, U64);
+            if (evals64 && hipMemcpyAsync(evals64, dev_ev, (size_t)n * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = PG_EHIP;
+            if (hipGetLastError() != hipSuccess) rc = PG_EHIP;
+        }
+        if (rc == PG_EHIP) set_error("pg_syevd_dev: output stage failed");
+    }
+    mark("outputs");
+    cleanup();
+    mark("free");
+    return rc;
+}
+
+#ifndef PG_SYEVD2_MIN_N
+#define PG_SYEVD2_MIN_N 1000000  // (two-stage path not yet faster than the one-stage reduction: opt-in with PG_SYEVD_STAGES=2)
+#endif
+#ifndef PG_SYEVD2_MAX_N
+#define PG_SYEVD2_MAX_N 24000    // work space of the two-stage path ~ 12 n^2 doubles
+#endif
+extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *evals, float *U, double *evals64, double *U64)
+{
+    PG_REQUIRE(ctx && K && (evals || evals64), "pg_syevd_dev: NULL argument");
+    PG_REQUIRE(n64 >= 1 && n64 <= 65535, "pg_syevd_dev: n=%lld out of range", (long long)n64);
+    PG_HIP(hipSetDevice(ctx->device));
+    const int n0 = (int)n64;
+    // PG_SYEVD_STAGES=1 | 2 forces a path (tests, A/B timing); by default the size decides
+    const char *force = getenv("PG_SYEVD_STAGES");
+    bool two = n0 >= PG_SYEVD2_MIN_N && n0 <= PG_SYEVD2_MAX_N;
+    if (force && force[0] == '1') two = false;
+    if (force && force[0] == '2') two = n0 >= 3 * SB_B;
+    if (two) {
+        const int rc = syevd_twostage(ctx, n0, K, evals, U, evals64, U64);
+        if (rc != PG_RETRY_ONESTAGE) return rc;
+    }
+    return syevd_onestage(ctx, n0, K, evals, U, evals64, U64);
+}
+
+// ---- test hooks of the two-stage pieces -------------------------------------------------------------------------------------------
+// stage 1 alone: K (n x n float32, lower triangle read) -> Aband (n x n fp64: the band |i - j| <= 64 of the result is meaningful);
+// if Z (n x n fp64) is given it is replaced by Q1 Z.  flags[4] (host): [0] panel factorisation flag.
+extern "C" int pgx_sb2_stage1_dev(pg_ctx *ctx, int64_t n64, const float *K, double *Aband, double *Z, int *flags)
+{
+    PG_REQUIRE(ctx && K && Aband && flags && n64 >= 3 * SB_B && n64 <= 65535, "pgx_sb2_stage1_dev: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    const int n = (int)n64;
+    Sb2Work sw;
+    int rc = sb2_alloc(n, sw);
+    if (rc) return rc;
+    sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, ctx->stream>>>(n, n, K, Aband);
+    rc = sy2sb_device(ctx, n, Aband, sw);
+    if (!rc && Z) rc = bt1_device(ctx, n, Z, sw);
+    if (!rc && hipMemcpyAsync(flags, sw.fail, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = PG_EHIP;
+    (void)hipStreamSynchronize(ctx->stream);
+    sb2_free(sw);
+    return rc;
+}
+
+// stage 2 alone: Aband (n x n fp64, only its band |i - j| <= 64, lower part, is read) -> d (n), e (n - 1) on the device;
+// if Z is given it is replaced by Q2 Z.
+extern "C" int pgx_sb2_stage2_dev(pg_ctx *ctx, int64_t n64, const double *Aband, double *d, double *e, double *Z, int *flags)
+{
+    PG_REQUIRE(ctx && Aband && d && e && flags && n64 >= 3 && n64 <= 65535, "pgx_sb2_stage2_dev: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    const int n = (int)n64;
+    Sb2Work sw;
+    int rc = sb2_alloc(n, sw);
+    if (rc) return rc;
+    if (hipMemsetAsync(sw.fail, 0, 4 * sizeof(int), ctx->stream) != hipSuccess) rc = PG_EHIP;
+    if (!rc) rc = sb2st_device(ctx, n, Aband, d, e, sw);
+    if (!rc && Z) rc = bt2_device(ctx, n, Z, sw);
+    if (!rc && hipMemcpyAsync(flags, sw.fail, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = PG_EHIP;
+    (void)hipStreamSynchronize(ctx->stream);
+    sb2_free(sw);
+    return rc;
+}
+
+// debugging aid: p = host-mapped memory (pg_host_alloc) of >= 4 ints, or NULL; the bulge-chasing kernel then records (sweep, step, phase)
+extern "C" int pgx_sb2_set_debug(void *p) { sb2_set_debug((int *)p); return PG_OK; }

@@ -35,6 +35,28 @@ def panel(n, p, c, seed=SEED, null=False, p_k=None, h2=0.5):
     return {"Y": y.reshape(-1, 1).astype(np.float32), "X": X, "W": W.astype(np.float32), "K": K.astype(np.float32)}
 
 
+def exact_panel(n, p, c, seed=SEED, p_k=None):
+    """Raw inputs of lmm.pygemma that regenerate BIT FOR BIT from a seed on any host (the big Tier-C fixtures store only the seed, Y, W
+    and the reference's output columns): X = raw hard calls 0/1/2 as float32; K = C C' / p_k with C = codes - 1 in {-1, 0, 1}
+    — every partial sum of the float32 product is an integer below 2^24, so the result does not depend on the BLAS, its threading
+    or its summation order; one rounding in the division.  Returns dict(X, K, C) — Y and W come from the fixture (their fp64
+    matrix-vector sums are not order-independent)."""
+    rng = np.random.default_rng(seed)
+    p_k = p_k or 2 * n
+    assert p_k < (1 << 24)
+    Cm = np.empty((n, p_k), np.float32)
+    for s0 in range(0, p_k, 4096):
+        e0 = min(p_k, s0 + 4096)
+        thr = rng.uniform(0.05, 0.5, e0 - s0)
+        u = rng.random((2, n, e0 - s0), dtype=np.float32)
+        Cm[:, s0:e0] = (u[0] < thr).astype(np.float32) + (u[1] < thr).astype(np.float32) - 1.0
+    K = (Cm @ Cm.T) / np.float32(p_k)
+    thr = rng.uniform(0.05, 0.5, p)
+    u = rng.random((2, n, p), dtype=np.float32)
+    X = (u[0] < thr).astype(np.float32) + (u[1] < thr).astype(np.float32)
+    return {"X": np.ascontiguousarray(X), "K": np.ascontiguousarray(K, np.float32), "C": Cm}
+
+
 def rotated_panel(n, p, c, seed=SEED, null=False, h2=0.5):
     """Eigen-basis inputs (the reference's eigen=False entry, lmm/lmm.py:164-167): d (n,), Xr (n,p), Yr, Wr.
     Rotation done in float64 on the host (input preparation for kernels that start at that boundary)."""

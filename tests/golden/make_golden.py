@@ -182,6 +182,47 @@ def gen_eigen_true():
     print("eigen_true_n300.npz")
 
 
+def gen_eigen_true_big(n, p=256, c=5, seed=9001):
+    """Tier C at the configs' n: the REAL reference with eigen=True (float32 ssyevr + sgemm inside) on inputs that
+    synth.exact_panel regenerates bit for bit from the seed on the GPU box.  Stored: the seed, Y, W, a checksum of K, the reference's
+    six columns (Brent and grid) and an fp64 'truth' pipeline (host dsyevd + fp64 rotation + the oracle in the reference's order)
+    for beta, se_beta, p_wald, so that the GPU test needs no n = 10 000 host eigendecomposition."""
+    import time
+    from oracle import oracle as O
+    ex = synth.exact_panel(n, p, c, seed=seed)
+    X, K, Cm = ex["X"], ex["K"], ex["C"]
+    rng = np.random.default_rng(seed + 1)
+    W = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, c - 1))], axis=1).astype(np.float32)
+    pk = Cm.shape[1]
+    b = rng.standard_normal(pk) * np.sqrt(0.5 / (pk * 0.4))
+    x0 = X[:, 0].astype(np.float64)
+    y = 0.25 * (x0 - x0.mean()) / max(x0.std(), 1e-9) + Cm.astype(np.float64) @ b + rng.standard_normal(n) * np.sqrt(0.5)
+    Y = y.astype(np.float32).reshape(-1, 1)
+    del Cm
+    out = {"versions": VERS, "seed": np.int64(seed), "n": np.int64(n), "p": np.int64(p), "c": np.int64(c), "Y": Y, "W": W,
+           "K_sum": np.float64(K.astype(np.float64).sum()), "K_trace": np.float64(np.trace(K.astype(np.float64)))}
+    for grid in (False, True):
+        t = time.time()
+        df = quiet(ref.pygemma, Y, X, W, K, grid=grid, eigen=True, nproc=1)
+        print(f"  reference n={n} grid={grid}: {time.time() - t:.1f} s", flush=True)
+        for col in ["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"]:
+            out[("grid_" if grid else "brent_") + col] = df[col].to_numpy()
+    t = time.time()
+    K64 = np.tril(K.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
+    d, U = np.linalg.eigh(K64)
+    print(f"  fp64 eigh n={n}: {time.time() - t:.1f} s", flush=True)
+    rot = lambda A: (U.T @ A.astype(np.float64)).astype(np.float32)
+    dY, dW, dX = rot(Y), rot(W), rot(X)
+    d32 = np.maximum(d, 0).astype(np.float32)
+    for grid in (False, True):
+        truth = O.calculate(d32, dY, dW, dX, grid=grid, order=0, nthreads=8)
+        for col in ["beta", "se_beta", "p_wald", "lambda"]:
+            out[("truth_grid_" if grid else "truth_brent_") + col] = np.asarray(truth[col])
+    name = f"eigen_true_exact_n{n}.npz"
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+
+
 def gen_eigen_true_imputed():
     """Tier C fixtures for the two other input classes of the rotation: raw 0/1/2 calls with missing entries imputed by the
     column mean (what the reference's callers feed, experiments/benchmarks/benchmarks.py:233-244) and continuous dosages
@@ -377,3 +418,8 @@ def gen_degenerate():
 
 if __name__ == "__main__" and "degenerate" in sys.argv[1:]:
     gen_degenerate()
+
+
+if __name__ == "__main__" and "eigen_big" in sys.argv[1:]:
+    for nn in (2000, 10000):
+        gen_eigen_true_big(nn)
