@@ -404,20 +404,22 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
 }
 
 // ---- band storage ---------------------------------------------------------------------------------------------------------------
-// S[i][o], o = j - i + (SB_LD - 1) for j <= i, i - j < SB_LD: the band (i - j <= b) from A, zeros in the room for the bulge
+// Row i of S holds the 128 columns j in (i - 128, i] of row i, column j in slot j & 127 (a circular window: the slot does not
+// move when the window does): the band (i - j <= b) from A, zeros in the room for the bulge.  A whole row is 1 KB, 16-byte aligned
+// for every i, so one wavefront moves one row with one 16-byte access per lane.
 __global__ void band_extract_kernel(int n, const double *A, double *S)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)(n + 2) * SB_LD) return;
-    const int i = (int)(idx / SB_LD), o = (int)(idx % SB_LD);
-    const int j = i - (SB_LD - 1) + o;
+    const int i = (int)(idx / SB_LD), p = (int)(idx % SB_LD);
+    const int j = i - ((i - p) & (SB_LD - 1));
     S[idx] = (i < n && j >= 0 && i - j <= B) ? A[(size_t)i * n + j] : 0.0;
 }
 __global__ void band_de_kernel(int n, const double *S, double *d, double *e)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) d[i] = S[(size_t)i * SB_LD + SB_LD - 1];
-    if (i + 1 < n) e[i] = S[(size_t)(i + 1) * SB_LD + SB_LD - 2];
+    if (i < n) d[i] = S[(size_t)i * SB_LD + (i & (SB_LD - 1))];
+    if (i + 1 < n) e[i] = S[(size_t)(i + 1) * SB_LD + (i & (SB_LD - 1))];
 }
 
 // ---- stage 2: bulge chasing -------------------------------------------------------------------------------------------------------
@@ -430,10 +432,24 @@ __device__ __forceinline__ void st_sc1(double *p, double v)
 {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int BC_SC1 = 16;     // aux bits of the raw buffer accesses: sc1
+__device__ __forceinline__ void unpack2(u32x4 v, double &a, double &b) { a = __hiloint2double((int)v.y, (int)v.x); b = __hiloint2double((int)v.w, (int)v.z); }
+__device__ __forceinline__ u32x4 pack2(double a, double b)
+{
+    u32x4 v;
+    v.x = (unsigned)__double2loint(a); v.y = (unsigned)__double2hiint(a); v.z = (unsigned)__double2loint(b); v.w = (unsigned)__double2hiint(b);
+    return v;
+}
 constexpr int BC_DONE = INT_MAX / 2;
 // debugging aid (pgx_sb2_set_debug): a host-mapped int array the bulge-chasing kernel leaves its position in (sweep, step, phase)
 static int *g_bc_debug = nullptr;
 void sb2_set_debug(int *p) { g_bc_debug = p; }
+#ifndef PG_BC_TIME
+#define BC_T(ix) do { } while (0)
+#else
+#define BC_T(ix) do { if (tid == 0) { const long long t_ = wall_clock64(); tacc[ix] += t_ - tlast; tlast = t_; } } while (0)
+#endif
 #ifndef PG_BC_DEBUG
 #define BC_HB(ph) do { } while (0)
 #else
@@ -442,29 +458,72 @@ void sb2_set_debug(int *p) { g_bc_debug = p; }
 #endif
 
 // prog[s] = number of completed steps of sweep s (BC_DONE when the sweep has ended); ctl[1] = abort flag.
-__global__ __launch_bounds__(256) void bc_kernel(int n, double *S, double *VV, double *TAU, int nk, int *prog, int *ctl, int *fail, int *dbg)
+constexpr int WP = SB_LD + 1;       // LDS pitch of one band row (129 doubles: rows and columns both walk conflict-free)
+#ifndef PG_BC_WAVES
+#define PG_BC_WAVES 16              // wavefronts per workgroup: several per SIMD hide each other's LDS latency (busy time per step at n = 10 000: 4 waves 8.4 us, 8: 5.2, 16: 4.9)
+#endif
+constexpr int NW = PG_BC_WAVES, RW = B / NW;     // RW: rows (or columns) of a 64 x 64 block per wavefront
+constexpr int BC_LDS_BYTES = (B * WP + 4 * B + 2 * NW * B + 2) * 8;
+
+// sum over the 64 lanes, returned to every lane: DPP inside each row of 16 lanes (no LDS round trips), the four row sums
+// combined through scalar registers
+__device__ __forceinline__ double dpp_mov(double x, const int ctrl_sel)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    switch (ctrl_sel) {     // dpp_ctrl must be an immediate
+        case 0: lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
+        case 1: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); break;   // quad_perm [2,3,0,1]
+        case 2: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); break; // row_half_mirror
+        default: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); break; // row_mirror
+    }
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ double wave_sum_dpp(double x)
+{
+    x += dpp_mov(x, 0);
+    x += dpp_mov(x, 1);
+    x += dpp_mov(x, 2);
+    x += dpp_mov(x, 3);          // every lane: the sum of its row of 16
+    return (readlane_d(x, 0) + readlane_d(x, 16)) + (readlane_d(x, 32) + readlane_d(x, 48));
+}
+
+__global__ __launch_bounds__(64 * NW) void bc_kernel(int n, double *S, double *VV, double *TAU, int nk, int *prog, int *ctl, int *fail, int *dbg)
 {
     // 72 KB of LDS: dynamic, with the launch attribute raised — a STATIC allocation above 64 KB compiles but is not honoured at launch
-    // (accesses beyond 64 KB read 0 and drop writes: the sweep index kept there never advanced; first GPU run of this kernel)
+    // (accesses beyond 64 KB read 0 and drop writes; first GPU run of this kernel).
+    // Wn holds the step's 64 band rows exactly as they lie in memory (row r0 + rl, slot = column & 127): loading and storing are plain
+    // row copies, one 16-byte access per lane.  With eb = (r0 - 64) & 127 the row reads, from slot eb on and cyclically,
+    //     E(rl, c) = Wn[rl][(eb + c) & 127], c < 64        D(rl, c) = Wn[rl][(eb + 64 + c) & 127], c <= rl   (lower triangle only)
     extern __shared__ double bc_lds[];
-    double *E = bc_lds, *D = bc_lds + MAT;
-    double *vcur = D + MAT, *vprev = vcur + B, *wv = vprev + B, *qv = wv + B;
+    double *Wn = bc_lds;
+    double *vcur = Wn + B * WP, *vprev = vcur + B, *wv = vprev + B, *qv = wv + B;
     double (*part)[B] = reinterpret_cast<double (*)[B]>(qv + B);
-    double (*part2)[B] = part + 4;
-    double *sc = reinterpret_cast<double *>(part2 + 4);
-    const int tid = threadIdx.x, lane = tid & 63, q4 = tid >> 6;     // (lane, q4): one of 64 columns/rows x a quarter of the other index
-    const int ri = tid >> 2, c0 = (tid & 3) * 16;                    // (ri, c0): row ri, 16 consecutive columns from c0
+    double (*part2)[B] = part + NW;
+    double *sc = reinterpret_cast<double *>(part2 + NW);
+    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;     // (lane, wq): one of 64 columns/rows x one NW-th of the other index
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(S, 0, (int)((size_t)(n + 2) * SB_LD * 8), 0x00020000);   // wave-uniform
     // Sweeps are dealt round-robin: workgroup w takes sweeps w, w + G, w + 2G, ... in order, so the sweep a workgroup waits for
     // always belongs to its left neighbour, which is resident (the grid never exceeds one workgroup per CU of an otherwise idle
     // stream).  (A dynamic queue — lane 0 fetching the next sweep with an atomic, broadcast through LDS — was the first version:
     // the compiler rotated that `if (tid == 0)` region into the loop latch and sent the other 63 lanes of wave 0 into the next
     // iteration's barriers ahead of lane 0; the kernel re-ran sweep 0 for ever.  A scalar loop counter cannot diverge.)
+#ifdef PG_BC_TIME
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+#endif
     for (int s = blockIdx.x; s <= n - 3; s += gridDim.x) {
         double taup = 0.0;
         for (int k = 0;; k++) {
             const int r0 = s + 1 + k * B;
             if (r0 >= n) break;
             const int L = (n - r0 < B) ? n - r0 : B;
+            const int eb = (r0 - B) & (SB_LD - 1), db = r0 & (SB_LD - 1);
+            const int ecol = (eb + lane) & (SB_LD - 1), dcol = (db + lane) & (SB_LD - 1);     // this lane's column of E / of D
+#define EIX(rl_, c_) ((rl_) * WP + ((eb + (c_)) & (SB_LD - 1)))
+#define DIX(rl_, c_) ((rl_) * WP + ((db + (c_)) & (SB_LD - 1)))
             BC_HB(1);
             if (s > 0) {
                 // step (s, k) reads rows r0 .. r0 + 63: the last of them is the first row of step (s - 1, k + 1)
@@ -477,115 +536,131 @@ __global__ __launch_bounds__(256) void bc_kernel(int n, double *S, double *VV, d
                             if (atomicOr(&fail[1], 1) == 0) { fail[2] = s; fail[3] = k; }
                             break;
                         }
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(1);
                     }
                 }
                 __syncthreads();
             }
-            BC_HB(2);
-            // ---- load: E = rows r0.., columns r0-64 .. r0-1 (k >= 1);  D = rows/columns r0.. (lower triangle, mirrored)
+            BC_HB(2); BC_T(0);
+            // ---- load: wave wq copies rows RW wq .. RW wq + RW - 1 (all accesses in flight), rows past the end are zero
             {
-                const bool rok = ri < L;
-                const double *row = S + (size_t)(r0 + ri) * SB_LD;
-                if (k >= 1) {
+                u32x4 rv[RW];
 #pragma unroll
-                    for (int q = 0; q < 16; q++) {
-                        const int c = c0 + q;
-                        E[ri * P65 + c] = rok ? ld_sc1(row + (B - 1) + c - ri) : 0.0;       // o = (r0-64+c) - (r0+ri) + 127
-                    }
+                for (int rr = 0; rr < RW; rr++) {
+                    const int rl = RW * wq + rr;
+                    if (rl < L) rv[rr] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)(((r0 + rl) * SB_LD + 2 * lane) * 8), 0, BC_SC1);
+                    else rv[rr] = u32x4{0u, 0u, 0u, 0u};
                 }
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int c = c0 + q;
-                    if (c <= ri) {
-                        const double v = rok ? ld_sc1(row + (SB_LD - 1) + c - ri) : 0.0;   // o = c - ri + 127
-                        D[ri * P65 + c] = v;
-                        D[c * P65 + ri] = v;
-                    }
+                for (int rr = 0; rr < RW; rr++) {
+                    const int rl = RW * wq + rr;
+                    double v0, v1;
+                    unpack2(rv[rr], v0, v1);
+                    Wn[rl * WP + 2 * lane] = v0;
+                    Wn[rl * WP + 2 * lane + 1] = v1;
                 }
             }
             double x0 = 0.0;
-            if (k == 0 && tid < B) x0 = (tid < L) ? ld_sc1(S + (size_t)(r0 + tid) * SB_LD + (SB_LD - 2) - tid) : 0.0;   // (r0 + i, s): o = 126 - i
             __syncthreads();
-            BC_HB(3);
-            // ---- (1) right-apply the previous reflector to E: u = E vprev;  E -= taup u vprev'
+            BC_HB(3); BC_T(1);
+            // ---- (1) right-apply the previous reflector to E: u = E vprev;  E -= taup u vprev'   (lane = row, wq = RW columns)
             if (k >= 1) {
                 double s_ = 0.0;
 #pragma unroll
-                for (int c = 16 * q4; c < 16 * q4 + 16; c++) s_ = fma(E[lane * P65 + c], vprev[c], s_);
-                part[q4][lane] = s_;
+                for (int c = RW * wq; c < RW * wq + RW; c++) s_ = fma(Wn[EIX(lane, c)], vprev[c], s_);
+                part[wq][lane] = s_;
                 __syncthreads();
-                const double tu = taup * (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
+                double u = 0.0;
 #pragma unroll
-                for (int c = 16 * q4; c < 16 * q4 + 16; c++) E[lane * P65 + c] = fma(-tu, vprev[c], E[lane * P65 + c]);
-                if (q4 == 0) x0 = E[lane * P65];       // first column, updated by this thread itself
-            }
+                for (int w_ = 0; w_ < NW; w_++) u += part[w_][lane];
+                const double tu = taup * u;
+#pragma unroll
+                for (int c = RW * wq; c < RW * wq + RW; c++) Wn[EIX(lane, c)] = fma(-tu, vprev[c], Wn[EIX(lane, c)]);
+                if (wq == 0) x0 = Wn[EIX(lane, 0)];       // first column, updated by this thread itself
+            } else if (wq == 0) x0 = Wn[EIX(lane, B - 1)];   // k = 0: column s, the last column of E
             // ---- (2) reflector (wave 0)
-            if (q4 == 0) {
-                const double alpha = __shfl(x0, 0, 64);
-                const double xn2 = wave_sum64((lane >= 1) ? x0 * x0 : 0.0);
+            if (wq == 0) {
+                const double alpha = readlane_d(x0, 0);
+                const double xn2 = wave_sum_dpp((lane >= 1) ? x0 * x0 : 0.0);
                 double beta = alpha, tau = 0.0, scal = 0.0;
                 if (xn2 != 0.0) { beta = -copysign(sqrt(alpha * alpha + xn2), alpha); tau = (beta - alpha) / beta; scal = 1.0 / (alpha - beta); }
                 const double v = (lane == 0) ? 1.0 : x0 * scal;     // rows >= L carry x0 = 0
                 vcur[lane] = v;
                 if (lane == 0) { sc[0] = tau; sc[1] = beta; TAU[(size_t)s * nk + k] = tau; }
                 if (lane < L) VV[(size_t)s * n + r0 + lane] = v;
-                if (k >= 1) E[lane * P65] = (lane == 0) ? beta : 0.0;
-                else if (lane < L) st_sc1(S + (size_t)(r0 + lane) * SB_LD + (SB_LD - 2) - lane, (lane == 0) ? beta : 0.0);
+                Wn[EIX(lane, (k >= 1) ? 0 : B - 1)] = (lane == 0) ? beta : 0.0;
             }
             __syncthreads();
-            BC_HB(4);
+            BC_HB(4); BC_T(5);
             const double tau = sc[0];
-            // ---- (3a), (4a) column products with the new reflector: w = E'v, p = D v
+            // ---- (3a), (4a) column products with the new reflector: w = E'v, p = D v   (lane = column, wq = RW rows;
+            // D symmetric with its lower triangle stored)
             {
                 double sw = 0.0, sp = 0.0;
 #pragma unroll
-                for (int r = 16 * q4; r < 16 * q4 + 16; r++) {
+                for (int r = RW * wq; r < RW * wq + RW; r++) {
                     const double vr = vcur[r];
-                    sp = fma(D[r * P65 + lane], vr, sp);
-                    if (k >= 1) sw = fma(E[r * P65 + lane], vr, sw);
+                    sp = fma(Wn[(r >= lane) ? r * WP + dcol : DIX(lane, r)], vr, sp);
+                    if (k >= 1) sw = fma(Wn[r * WP + ecol], vr, sw);
                 }
-                part[q4][lane] = sw;
-                part2[q4][lane] = sp;
+                part[wq][lane] = sw;
+                part2[wq][lane] = sp;
             }
             __syncthreads();
-            if (q4 == 0) wv[lane] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-            if (q4 == 1) {
-                const double p = tau * (((part2[0][lane] + part2[1][lane]) + part2[2][lane]) + part2[3][lane]);
-                const double pv = wave_sum64(p * vcur[lane]);
+            BC_T(6);
+            if (wq == 0) {
+                double w_ = 0.0;
+#pragma unroll
+                for (int q = 0; q < NW; q++) w_ += part[q][lane];
+                wv[lane] = w_;
+            }
+            if (wq == 1) {
+                double p = 0.0;
+#pragma unroll
+                for (int q = 0; q < NW; q++) p += part2[q][lane];
+                p *= tau;
+                const double pv = wave_sum_dpp(p * vcur[lane]);
                 qv[lane] = p - 0.5 * tau * pv * vcur[lane];
             }
             __syncthreads();
-            BC_HB(5);
-            // ---- (3b), (4b) rank updates, written straight to the band (write-through)
-            if (ri < L) {
-                double *row = S + (size_t)(r0 + ri) * SB_LD;
-                const double vi = vcur[ri], qi = qv[ri], tvi = tau * vi;
-                if (k >= 1) {
+            BC_HB(5); BC_T(7);
+            // ---- (3b), (4b) rank updates in place (lane = column, wq = RW rows): this lane's w, q, v once, the rows' v, q broadcast
+            {
+                const double wc = wv[lane], qc = qv[lane], vc = vcur[lane];
 #pragma unroll
-                    for (int q = 0; q < 16; q++) {
-                        const int c = c0 + q;
-                        const double e = E[ri * P65 + c];
-                        st_sc1(row + (B - 1) + c - ri, (c == 0) ? e : fma(-tvi, wv[c], e));
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int c = c0 + q;
-                    if (c <= ri) st_sc1(row + (SB_LD - 1) + c - ri, D[ri * P65 + c] - (vi * qv[c] + qi * vcur[c]));
+                for (int r = RW * wq; r < RW * wq + RW; r++) {
+                    const double vr = vcur[r], qr = qv[r];
+                    if (k >= 1 && lane >= 1) Wn[r * WP + ecol] = fma(-tau * vr, wc, Wn[r * WP + ecol]);
+                    if (lane <= r) Wn[r * WP + dcol] -= vr * qc + qr * vc;
                 }
             }
             if (tid < B) vprev[tid] = vcur[tid];
             taup = tau;
+            __syncthreads();
+            BC_T(2);
+            // ---- store: rows back as they came (write-through 16-byte stores)
+#pragma unroll
+            for (int rr = 0; rr < RW; rr++) {
+                const int rl = RW * wq + rr;
+                if (rl >= L) break;
+                __builtin_amdgcn_raw_buffer_store_b128(pack2(Wn[rl * WP + 2 * lane], Wn[rl * WP + 2 * lane + 1]), rsrc,
+                                                       (unsigned)(((r0 + rl) * SB_LD + 2 * lane) * 8), 0, BC_SC1);
+            }
             // every storing wave drains its stores, the workgroup meets, then one lane publishes the step
-            BC_HB(6);
+            BC_HB(6); BC_T(3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            BC_HB(7);
+            BC_HB(7); BC_T(4);
             if (tid == 0) __hip_atomic_store(&prog[s], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#undef EIX
+#undef DIX
         }
         if (tid == 0) __hip_atomic_store(&prog[s], BC_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef PG_BC_TIME
+    if (dbg && tid == 0 && blockIdx.x == 1)      // 100 MHz ticks spent by workgroup 1, per phase
+        for (int q = 0; q < 8; q++) __hip_atomic_store(&dbg[4 + q], (int)(tacc[q] / 100), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
 }
 
 int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2Work &w)
@@ -600,13 +675,13 @@ int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2W
         int nwg = n / (2 * B) + 4;
         nwg = std::max(1, std::min(nwg, std::min(ctx->num_cu, 256)));
         if (const char *e_ = getenv("PG_BC_NWG")) nwg = std::max(1, std::min(atoi(e_), 256));     // A/B and debugging
-        constexpr int BC_LDS = (2 * MAT + 4 * B + 8 * B + 2) * 8;
+        constexpr int BC_LDS = BC_LDS_BYTES;
         static bool attr_done = false;
         if (!attr_done) {
             PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS));
             attr_done = true;
         }
-        bc_kernel<<<nwg, 256, BC_LDS, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.prog, w.prog + n, w.fail, g_bc_debug);
+        bc_kernel<<<nwg, 64 * NW, BC_LDS, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.prog, w.prog + n, w.fail, g_bc_debug);
     }
     band_de_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, w.S, d, e);
     PG_HIP(hipGetLastError());
