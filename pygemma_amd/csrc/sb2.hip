@@ -24,6 +24,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace pg {
 
@@ -33,13 +34,17 @@ constexpr int MAT = B * P65;     // doubles per LDS matrix
 constexpr int BT1_BLOCK = 256;   // reflectors per block of the stage-1 back-transformation
 
 // small matrices in w.sm (b x b each)
-enum { SM_G1 = 0, SM_R1, SM_R1INV, SM_G2, SM_XM, SM_M1, SM_M2, SM_COUNT };
+enum { SM_G1 = 0, SM_R1, SM_R1INV, SM_G2, SM_XM, SM_M1, SM_M2, SM_RPROD, SM_COUNT };
 
 __device__ __forceinline__ void wave_sync_lds()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double readlane_d(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
 __device__ __forceinline__ double wave_sum64(double v)
 {
@@ -121,23 +126,58 @@ __device__ __forceinline__ void load64(double *dst, const double *src, long long
     for (int q = 0; q < 16; q++) dst[i * P65 + j0 + q] = src[(long long)i * ld + j0 + q];
 }
 
-// ---- pass 1 of CholeskyQR2: G -> R1 (upper) and R1^-1 -----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_inv_kernel(const double *G, double *R, double *Rinv, int *fail)
+// row i of X by one lane: X U = rhs with U upper triangular (coefficients wave-uniform: LDS broadcast reads); a lane reads only
+// what it wrote itself, so the 64 rows of one wavefront need no synchronisation at all.  Called by ONE wavefront (lane = row).
+template <class UC, class UD, class RH>
+__device__ __forceinline__ void solve_rows_wave(double *X, UC ucoef, UD urcp, RH rhs, int lane)
+{
+    for (int j = 0; j < B; j++) {
+        double s0 = 0.0, s1 = 0.0;
+        int k = 0;
+        for (; k + 1 < j; k += 2) {
+            s0 = fma(X[lane * P65 + k], ucoef(k, j), s0);
+            s1 = fma(X[lane * P65 + k + 1], ucoef(k + 1, j), s1);
+        }
+        if (k < j) s0 = fma(X[lane * P65 + k], ucoef(k, j), s0);
+        X[lane * P65 + j] = (rhs(lane, j) - (s0 + s1)) * urcp(j);
+    }
+}
+
+// ---- pass 1 of CholeskyQR2: G -> R1 (upper) and R1^-1, one wavefront, no workgroup barriers --------------------------------
+// Row k of R from the rows above it (left-looking): lane j forms G[k][j] - sum_{i<k} R[i][k] R[i][j]; the pivot goes to every
+// lane through a scalar register.  Then X R = I row by row (solve_rows_wave).
+__global__ __launch_bounds__(64) void chol_inv_kernel(const double *G, double *R, double *Rinv, int *fail)
 {
     extern __shared__ double lds[];
     double *A = lds, *X = lds + MAT;
-    const int tid = threadIdx.x;
-    load64(A, G, B, tid);
-    __syncthreads();
-    const bool ok = chol_upper64(A, tid);
-    if (!ok && tid == 0) atomicOr(fail, 1);
-    solve_right_upper64(X, [&](int k, int j) { return A[k * P65 + j]; }, [&](int j) { return A[j * P65 + j]; },
-                        [&](int i, int j) { return i == j ? 1.0 : 0.0; }, tid);
-    const int i = tid >> 2, j0 = (tid & 3) * 16;
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        R[i * B + j0 + q] = A[i * P65 + j0 + q];
-        Rinv[i * B + j0 + q] = X[i * P65 + j0 + q];
+    __shared__ double rd[B];
+    const int lane = threadIdx.x;
+    for (int i = 0; i < B; i++) A[i * P65 + lane] = G[i * B + lane];
+    wave_sync_lds();
+    bool ok = true;
+    for (int k = 0; k < B; k++) {
+        double s0 = 0.0, s1 = 0.0;
+        int i = 0;
+        for (; i + 1 < k; i += 2) {
+            s0 = fma(A[i * P65 + k], A[i * P65 + lane], s0);
+            s1 = fma(A[(i + 1) * P65 + k], A[(i + 1) * P65 + lane], s1);
+        }
+        if (i < k) s0 = fma(A[i * P65 + k], A[i * P65 + lane], s0);
+        const double t = A[k * P65 + lane] - (s0 + s1);
+        const double tk = readlane_d(t, k);
+        const bool bad = !(tk > 0.0) || !(tk < 1.0e300);
+        ok = ok && !bad;
+        const double d = bad ? 1.0 : sqrt(tk), rcp = 1.0 / d;
+        A[k * P65 + lane] = (lane == k) ? d : ((lane > k) ? t * rcp : 0.0);
+        if (lane == 0) rd[k] = rcp;
+        wave_sync_lds();
+    }
+    if (!ok && lane == 0) atomicOr(fail, 1);
+    solve_rows_wave(X, [&](int k, int j) { return A[k * P65 + j]; }, [&](int j) { return rd[j]; },
+                    [&](int i, int j) { return i == j ? 1.0 : 0.0; }, lane);
+    for (int i = 0; i < B; i++) {
+        R[i * B + lane] = A[i * P65 + lane];
+        Rinv[i * B + lane] = (lane >= i) ? X[i * P65 + lane] : 0.0;
     }
 }
 
@@ -145,14 +185,16 @@ __global__ __launch_bounds__(256) void chol_inv_kernel(const double *G, double *
 // in : G2 = Q1'Q1, R1, Q1top = first 64 rows of Q1 (ld 64)
 // out: Rs = D R2 R1 into the band block Aband (ld lda; only the upper triangle is written), V's top block (unit lower) into VW (ld 2b)
 //      and Vst (ld ldv), T (64 x 64), Xm = -R2^-1 D U^-1 (so that the rows of V below the top block are Q1 Xm)
+// R2: when |G2 - I| < 1e-8 (every panel of a well-conditioned K) its first-order form I + triu(G2 - I, 1) + diag(G2 - I)/2 and
+// R2^-1 = 2I - R2 are exact to working precision (the neglected terms are of second order, < 1e-16); otherwise the Cholesky route.
 __global__ __launch_bounds__(256) void recon_kernel(const double *G2, const double *R1g, const double *Q1top, double *Aband, long long lda,
-                                                    double *VW, double *Vst, long long ldv, double *Tout, double *Xm, int *fail)
+                                                    double *VW, double *Vst, long long ldv, double *Tout, double *Xm, double *Rprod, int *fail)
 {
     extern __shared__ double lds[];
     double *M0 = lds, *M1 = lds + MAT, *M2 = lds + 2 * MAT, *M3 = lds + 3 * MAT;
-    __shared__ double Dg[B], piv[B];
+    __shared__ double Dg[B], piv[B], prc[B];
     __shared__ double red[4];
-    const int tid = threadIdx.x, i = tid >> 2, j0 = (tid & 3) * 16;
+    const int tid = threadIdx.x, i = tid >> 2, j0 = (tid & 3) * 16, lane = tid & 63, wave = tid >> 6;
     // orthogonality of pass 1 = |G2 - I|_max: CholeskyQR2 reaches working accuracy when this is well below 1
     double err = 0.0;
 #pragma unroll
@@ -163,48 +205,77 @@ __global__ __launch_bounds__(256) void recon_kernel(const double *G2, const doub
         err = (dlt > err || !(dlt == dlt)) ? dlt : err;      // a NaN sticks
     }
     for (int s = 1; s < 64; s <<= 1) { const double o = __shfl_xor(err, s, 64); err = (o > err || !(o == o)) ? o : err; }
-    if ((tid & 63) == 0) red[tid >> 6] = err;
-    __syncthreads();
-    if (tid == 0) {
-        double e = red[0];
-        for (int w = 1; w < 4; w++) e = (red[w] > e || !(red[w] == red[w])) ? red[w] : e;
-        if (!(e <= 0.05)) atomicOr(fail, 1);
-    }
-    const bool ok = chol_upper64(M0, tid);                                        // M0 = R2
-    if (!ok && tid == 0) atomicOr(fail, 1);
-    solve_right_upper64(M1, [&](int k, int j) { return M0[k * P65 + j]; }, [&](int j) { return M0[j * P65 + j]; },
-                        [&](int a, int b) { return a == b ? 1.0 : 0.0; }, tid);   // M1 = R2^-1
-    mm64([&](int a, int k) { return Q1top[a * B + k]; }, [&](int k, int b) { return M1[k * P65 + b]; },
-         [&](int a, int b, double v) { M2[a * P65 + b] = v; }, tid);               // M2 = top block of Q = Q1 R2^-1
+    if (lane == 0) red[wave] = err;
     load64(M3, R1g, B, tid);                                                      // M3 = R1
     __syncthreads();
-    // LU of E - Q D without pivoting on the top block, in place on M2: below the diagonal -> L (= V's top block), on and above -> the
-    // eliminated entries q~ of Q with U[i][j] = -D_j q~[i][j] (i < j), U[j][j] = piv_j = 1 + |q~_jj|
-    for (int j = 0; j < B; j++) {
-        const double qjj = M2[j * P65 + j];
-        const double dj = (qjj >= 0.0) ? -1.0 : 1.0, pv = 1.0 - dj * qjj;
+    double e_all = red[0];
+    for (int w = 1; w < 4; w++) e_all = (red[w] > e_all || !(red[w] == red[w])) ? red[w] : e_all;
+    if (tid == 0 && !(e_all <= 0.05)) atomicOr(fail, 1);
+    if (e_all < 1.0e-8) {
         __syncthreads();
-        if (tid == 0) { Dg[j] = dj; piv[j] = pv; }
-        if (tid < B && tid > j) M2[tid * P65 + j] = -dj * M2[tid * P65 + j] / pv;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = j0 + q;
+            const double g = M0[i * P65 + c];
+            const double r2 = (c > i) ? g : ((c == i) ? 1.0 + 0.5 * (g - 1.0) : 0.0);
+            M0[i * P65 + c] = r2;                                                 // M0 = R2
+            M1[i * P65 + c] = (c == i) ? 2.0 - r2 : -r2;                          // M1 = R2^-1 = 2I - R2
+        }
         __syncthreads();
-        if (i > j) {
-            const double lij = M2[i * P65 + j];
-#pragma unroll 4
-            for (int c = j0; c < j0 + 16; c++)
-                if (c > j) M2[i * P65 + c] -= lij * M2[j * P65 + c];
+    } else {
+        const bool ok = chol_upper64(M0, tid);                                    // M0 = R2
+        if (!ok && tid == 0) atomicOr(fail, 1);
+        solve_right_upper64(M1, [&](int k, int j) { return M0[k * P65 + j]; }, [&](int j) { return M0[j * P65 + j]; },
+                            [&](int a, int b) { return a == b ? 1.0 : 0.0; }, tid);   // M1 = R2^-1
+    }
+    mm64([&](int a, int k) { return Q1top[a * B + k]; }, [&](int k, int b) { return M1[k * P65 + b]; },
+         [&](int a, int b, double v) { M2[a * P65 + b] = v; }, tid);               // M2 = top block of Q = Q1 R2^-1
+    mm64([&](int a, int k) { return M0[a * P65 + k]; }, [&](int k, int b) { return M3[k * P65 + b]; },
+         [&](int a, int b, double v) { Rprod[a * B + b] = v; }, tid);              // R2 R1 (scaled by D on the way out)
+    __syncthreads();
+    // LU of E - Q D without pivoting on the top block, in place on M2 (Crout order, two wavefronts): after step k row k holds the
+    // eliminated entries W[k][j] = q~_j[k] of Q for j >= k (U[k][j] = -D_j W[k][j], U[k][k] = piv_k = 1 + |W[k][k]|), column k the
+    // multipliers L[r][k], r > k (= V's top block).  Wave 0: row k (lane = column); wave 1: column k (lane = row).
+    for (int k = 0; k < B; k++) {
+        double val = 0.0;
+        if (wave == 0) {
+            double s0 = 0.0, s1 = 0.0;
+            int t = 0;
+            for (; t + 1 < k; t += 2) {
+                s0 = fma(M2[k * P65 + t], M2[t * P65 + lane], s0);
+                s1 = fma(M2[k * P65 + t + 1], M2[(t + 1) * P65 + lane], s1);
+            }
+            if (t < k) s0 = fma(M2[k * P65 + t], M2[t * P65 + lane], s0);
+            val = M2[k * P65 + lane] - (s0 + s1);
+        } else if (wave == 1) {
+            double s0 = 0.0, s1 = 0.0;
+            int t = 0;
+            for (; t + 1 < k; t += 2) {
+                s0 = fma(M2[lane * P65 + t], M2[t * P65 + k], s0);
+                s1 = fma(M2[lane * P65 + t + 1], M2[(t + 1) * P65 + k], s1);
+            }
+            if (t < k) s0 = fma(M2[lane * P65 + t], M2[t * P65 + k], s0);
+            val = M2[lane * P65 + k] - (s0 + s1);
+        }
+        __syncthreads();                                   // all reads of this step done
+        if (wave == 0 && lane >= k) M2[k * P65 + lane] = val;
+        __syncthreads();
+        if (wave == 1) {
+            const double wkk = M2[k * P65 + k];
+            const double dk = (wkk >= 0.0) ? -1.0 : 1.0, pv = 1.0 - dk * wkk, rc = 1.0 / pv;
+            if (lane > k) M2[lane * P65 + k] = -dk * val * rc;
+            if (lane == 0) { Dg[k] = dk; piv[k] = pv; prc[k] = rc; }
         }
         __syncthreads();
     }
-    // Rs = D (R2 R1): the band block below the diagonal block of this panel (upper triangular)
-    mm64([&](int a, int k) { return M0[a * P65 + k]; }, [&](int k, int b) { return M3[k * P65 + b]; },
-         [&](int a, int b, double v) { if (b >= a) Aband[(long long)a * lda + b] = Dg[a] * v; }, tid);
+    // T = U Y1^-T: T Y1' = U, Y1' unit upper triangular with Y1'[k][j] = L[j][k]  (wave 0 -> M0);  Xm U = -R2^-1 D  (wave 1 -> M3)
+    if (wave == 0)
+        solve_rows_wave(M0, [&](int k, int j) { return M2[j * P65 + k]; }, [&](int) { return 1.0; },
+                        [&](int a, int b) { return (a == b) ? piv[b] : ((a < b) ? -Dg[b] * M2[a * P65 + b] : 0.0); }, lane);
+    else if (wave == 1)
+        solve_rows_wave(M3, [&](int k, int j) { return -Dg[j] * M2[k * P65 + j]; }, [&](int j) { return prc[j]; },
+                        [&](int a, int b) { return -M1[a * P65 + b] * Dg[b]; }, lane);
     __syncthreads();
-    // T = U Y1^-T: T Y1' = U, Y1' unit upper triangular with Y1'[k][j] = L[j][k]                     -> M0
-    solve_right_upper64(M0, [&](int k, int j) { return M2[j * P65 + k]; }, [&](int) { return 1.0; },
-                        [&](int a, int b) { return (a == b) ? piv[b] : ((a < b) ? -Dg[b] * M2[a * P65 + b] : 0.0); }, tid);
-    // Xm U = -R2^-1 D                                                                              -> M3
-    solve_right_upper64(M3, [&](int k, int j) { return -Dg[j] * M2[k * P65 + j]; }, [&](int j) { return piv[j]; },
-                        [&](int a, int b) { return -M1[a * P65 + b] * Dg[b]; }, tid);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int c = j0 + q;
@@ -213,6 +284,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const double *G2, const doub
         const double v = (i == c) ? 1.0 : ((i > c) ? M2[i * P65 + c] : 0.0);
         VW[(long long)i * (2 * B) + c] = v;
         Vst[(long long)i * ldv + c] = v;
+        if (c >= i) Aband[(long long)i * lda + c] = Dg[i] * Rprod[i * B + c];     // Rs = D (R2 R1): written by this same thread above
     }
 }
 
@@ -372,11 +444,11 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
             // CholeskyQR2: G1 = P'P, R1; Q1 = P R1^-1; G2 = Q1'Q1, R2; (Q = Q1 R2^-1 only through its top block and Xm)
             rc = dgemm(ctx, true, B, B, m, 1.0, P, ld, P, ld, 0.0, SM(SM_G1), B);
             if (rc) return rc;
-            chol_inv_kernel<<<1, 256, 2 * MAT * 8, st>>>(SM(SM_G1), SM(SM_R1), SM(SM_R1INV), w.fail);
+            chol_inv_kernel<<<1, 64, 2 * MAT * 8, st>>>(SM(SM_G1), SM(SM_R1), SM(SM_R1INV), w.fail);
             rc = dgemm(ctx, false, m, B, B, 1.0, P, ld, SM(SM_R1INV), B, 0.0, w.Qb, B);
             if (!rc) rc = dgemm(ctx, true, B, B, m, 1.0, w.Qb, B, w.Qb, B, 0.0, SM(SM_G2), B);
             if (rc) return rc;
-            recon_kernel<<<1, 256, LDS4, st>>>(SM(SM_G2), SM(SM_R1), w.Qb, P, ld, w.VW, Vs, ld, Tp, SM(SM_XM), w.fail);
+            recon_kernel<<<1, 256, LDS4, st>>>(SM(SM_G2), SM(SM_R1), w.Qb, P, ld, w.VW, Vs, ld, Tp, SM(SM_XM), SM(SM_RPROD), w.fail);
             // rows 64.. of V = Q1[64:, :] Xm  -> VW[:, 0:64]
             rc = dgemm(ctx, false, m - B, B, B, 1.0, w.Qb + (size_t)B * B, B, SM(SM_XM), B, 0.0, w.VW + (size_t)B * 2 * B, 2 * B);
             if (rc) return rc;
@@ -477,10 +549,6 @@ __device__ __forceinline__ double dpp_mov(double x, const int ctrl_sel)
         default: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); break; // row_mirror
     }
     return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_d(double x, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
 __device__ __forceinline__ double wave_sum_dpp(double x)
 {
@@ -754,6 +822,168 @@ __global__ __launch_bounds__(256) void bt2_prep_kernel(int n, int nk, int ng, co
     }
 }
 
+// One reflector block applied to one slab of 64 columns of Z in ONE pass:  Zs <- Zs - (V T) (V' Zs).
+// The slab (127 rows x 64 columns) is read from HBM once, into REGISTERS, in the accumulator layout of the fp64 MFMA (a 16 x 16 tile:
+// lane l, component e = row (l >> 4) + 4 e, column l & 15) — which is also the layout of its B operand for the four k-steps of a
+// 16-row tile, so W = V' Zs needs no LDS copy of the slab, and the same registers are the C operand of the second product.
+// W (64 x 64) goes through LDS; V and V T (128 x 64 each, L2-resident: every slab of the block reads the same two) are staged in
+// chunks of 16 k-rows like dgemm's operands.  Four waves as 2 x 2; 76 KB of LDS: two workgroups per CU overlap each other's slab
+// traffic.  History at n = 10 000: two batched GEMMs per wavefront (40 MB of HBM traffic per block) 166 ms; fused with the slab in
+// LDS (one workgroup per CU, nothing overlapped) 142 ms; this version: see DESIGN.
+constexpr int BT2_NS = 64;                 // columns of Z per workgroup
+constexpr int BT2_ZP = BT2_NS + 16;        // LDS pitch of W: consecutive k-rows on disjoint bank halves (as in dgemm.hpp)
+constexpr int BT2_AP = 128 + 16;           // pitch of a staged operand chunk [CK][128]
+constexpr int BT2_CK = 16;                 // k-rows per staged operand chunk
+constexpr int BT2_LDS_BYTES = (64 * BT2_ZP + 2 * BT2_CK * BT2_AP) * 8;
+struct Bt2Args {
+    int n, nb;
+    long long row_first, h_last;
+    const double *Vp, *Vtp;       // block of batch element 0
+    long long blk_stride;         // elements between consecutive batch elements
+    double *Z;
+};
+__global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
+{
+    extern __shared__ double lds[];
+    double *Ws = lds;                               // [64][ZP]    Ws[sweep][c]
+    double *As = Ws + 64 * BT2_ZP;                  // [2][CK][AP] operand chunk, k-major
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.y, n = ar.n;
+    const long long row0 = ar.row_first + (long long)z * (B + SB_G);
+    const int h = (z == ar.nb - 1) ? (int)ar.h_last : B + SB_G - 1;
+    const int c0 = blockIdx.x * BT2_NS, ncols = (n - c0 < BT2_NS) ? n - c0 : BT2_NS;
+    const double *V = ar.Vp + (long long)z * ar.blk_stride, *Vt = ar.Vtp + (long long)z * ar.blk_stride;
+    double *Zg = ar.Z + (size_t)row0 * n + c0;
+    constexpr int CK = BT2_CK, NA = 128 / CK, NB2 = SB_G / CK;
+    // ---- slab in: this wave's 32 columns of all 128 rows (8 row tiles x 2 column tiles)
+    doublex4 zr[8][2];
+    const int rsub = lane >> 4, csub = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int col = wn * 32 + j * 16 + csub;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = t * 16 + rsub + 4 * e;
+                zr[t][j][e] = (row < h && col < ncols) ? Zg[(size_t)row * n + col] : 0.0;
+            }
+        }
+    // ---- phase A: W (64 sweeps x 64 columns) = V' Zs, K = 128 rows; operand chunk = CK rows of V (contiguous doubles)
+    doublex4 accA[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) accA[i][j][e] = 0.0;
+    double2 stg[CK / 8];
+    auto gloadA = [&](int kt) {      // chunk kt: rows CK kt ..: CK * 64 contiguous doubles; thread -> double2 number tid (+ 256 per pass)
+#pragma unroll
+        for (int ps = 0; ps < CK / 8; ps++) stg[ps] = *reinterpret_cast<const double2 *>(V + (size_t)kt * CK * SB_G + 2 * (ps * 256 + tid));
+    };
+    auto lstoreA = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < CK / 8; ps++) {
+            const int e0 = 2 * (ps * 256 + tid);           // element of the chunk: row e0 / 64, sweep e0 % 64
+            double *d = As + (buf * CK + (e0 >> 6)) * BT2_AP + (e0 & 63);
+            d[0] = stg[ps].x; d[1] = stg[ps].y;
+        }
+    };
+    gloadA(0);
+    lstoreA(0);
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < NA; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < NA) gloadA(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < CK; kk += 4) {
+            const int kr = kk + rsub;
+            double a[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) a[i] = As[(buf * CK + kr) * BT2_AP + wm * 32 + i * 16 + csub];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    accA[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], zr[(kt * CK + kk) / 16][j][((kt * CK + kk) % 16) / 4], accA[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < NA) lstoreA(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                Ws[(wm * 32 + i * 16 + rsub + 4 * e) * BT2_ZP + wn * 32 + j * 16 + csub] = accA[i][j][e];
+    // ---- phase B: Zs (128 x 64) -= (V T) W, K = 64 sweeps; operand chunk = CK sweeps of all 128 rows of V T (row-major [row][sweep])
+    doublex4 accB[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) accB[i][j][e] = 0.0;
+    double rt[CK / 8][4];
+    auto gloadB = [&](int kt) {      // thread -> row tid / 2, 4 consecutive sweeps (+ 8 per pass)
+#pragma unroll
+        for (int ps = 0; ps < CK / 8; ps++) {
+            const double *src = Vt + (size_t)(tid >> 1) * SB_G + kt * CK + ps * 8 + (tid & 1) * 4;
+            const double2 a = *reinterpret_cast<const double2 *>(src), b2 = *reinterpret_cast<const double2 *>(src + 2);
+            rt[ps][0] = a.x; rt[ps][1] = a.y; rt[ps][2] = b2.x; rt[ps][3] = b2.y;
+        }
+    };
+    auto lstoreB = [&](int buf) {
+#pragma unroll
+        for (int ps = 0; ps < CK / 8; ps++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) As[(buf * CK + ps * 8 + (tid & 1) * 4 + q) * BT2_AP + (tid >> 1)] = rt[ps][q];
+    };
+    gloadB(0);
+    lstoreB(0);
+    __syncthreads();          // also: W complete in LDS
+#pragma unroll
+    for (int kt = 0; kt < NB2; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < NB2) gloadB(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < CK; kk += 4) {
+            const int kr = kk + rsub;
+            double a[4], b2[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = As[(buf * CK + kr) * BT2_AP + wm * 64 + i * 16 + csub];
+#pragma unroll
+            for (int j = 0; j < 2; j++) b2[j] = Ws[(kt * CK + kr) * BT2_ZP + wn * 32 + j * 16 + csub];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) accB[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b2[j], accB[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < NB2) lstoreB(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- slab out: this wave's rows 64 wm .. 64 wm + 63 (row tiles 4 wm + i of the registers)
+    auto store_rows = [&](auto WM) {
+        constexpr int wmc = decltype(WM)::value;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = wn * 32 + j * 16 + csub;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int row = wmc * 64 + i * 16 + rsub + 4 * e;
+                    if (row < h && col < ncols) Zg[(size_t)row * n + col] = zr[wmc * 4 + i][j][e] - accB[i][j][e];
+                }
+            }
+    };
+    if (wm == 0) store_rows(std::integral_constant<int, 0>{});
+    else store_rows(std::integral_constant<int, 1>{});
+}
+
 int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w)
 {
     if (n < 3) return PG_OK;
@@ -764,12 +994,14 @@ int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w)
     static bool attr_done = false;
     if (!attr_done) {
         PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS_BYTES));
         attr_done = true;
     }
     bt2_prep_kernel<<<dim3(ng, kmax), 256, lds, st>>>(n, w.nk, ng, w.VV, w.TAU, w.Vp, w.Vtp);
     PG_HIP(hipGetLastError());
     const size_t blk = (size_t)VR * SB_G;
     const int glast = ng - 1;
+    const int nslab = (n + BT2_NS - 1) / BT2_NS;
     // wavefront t: blocks (G, k) with (glast - G) + k = t; their rows start (g + b) apart
     for (int t = 0;; t++) {
         const int kmin = std::max(0, t - glast);
@@ -781,25 +1013,14 @@ int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w)
         if (kmx < kmin) break;     // wavefronts are non-empty up to the last one (t <= glast: k = 0 exists; beyond: once empty, always empty)
         const int nb = (int)(kmx - kmin + 1);
         const long long row_first = base + (long long)kmin * (SB_G + B), row_last = base + kmx * (SB_G + B);
-        const long long h_last = std::min<long long>(HGT, n - row_last);
         const int G0 = glast - t + kmin;
-        DgemmDesc d1;                               // W_z = V_z' Z[rows_z, :]
-        d1.transA = true; d1.M = SB_G; d1.N = n; d1.K = HGT; d1.alpha = 1.0; d1.beta = 0.0;
-        d1.A = w.Vp + ((size_t)kmin * ng + G0) * blk; d1.lda = SB_G; d1.strideA = (long long)(ng + 1) * blk;
-        d1.B = Z + (size_t)row_first * n; d1.ldb = n; d1.strideB = (long long)(SB_G + B) * n;
-        d1.C = w.Wws; d1.ldc = n; d1.strideC = (long long)SB_G * n;
-        d1.nbatch = nb; d1.K_last = h_last; d1.allow_splitk = false;
-        int rc = dgemm_ex(ctx, d1);
-        if (rc) return rc;
-        DgemmDesc d2;                               // Z[rows_z, :] -= (V T)_z W_z
-        d2.M = HGT; d2.N = n; d2.K = SB_G; d2.alpha = -1.0; d2.beta = 1.0;
-        d2.A = w.Vtp + ((size_t)kmin * ng + G0) * blk; d2.lda = SB_G; d2.strideA = (long long)(ng + 1) * blk;
-        d2.B = w.Wws; d2.ldb = n; d2.strideB = (long long)SB_G * n;
-        d2.C = Z + (size_t)row_first * n; d2.ldc = n; d2.strideC = (long long)(SB_G + B) * n;
-        d2.nbatch = nb; d2.M_last = h_last; d2.allow_splitk = false;
-        rc = dgemm_ex(ctx, d2);
-        if (rc) return rc;
+        Bt2Args ar;
+        ar.n = n; ar.nb = nb; ar.row_first = row_first; ar.h_last = std::min<long long>(HGT, n - row_last);
+        ar.Vp = w.Vp + ((size_t)kmin * ng + G0) * blk; ar.Vtp = w.Vtp + ((size_t)kmin * ng + G0) * blk;
+        ar.blk_stride = (long long)(ng + 1) * blk; ar.Z = Z;
+        bt2_apply_kernel<<<dim3(nslab, nb), 256, BT2_LDS_BYTES, st>>>(ar);
     }
+    PG_HIP(hipGetLastError());
     return PG_OK;
 }
 
