@@ -8,8 +8,11 @@
 //   batch      : blockIdx.z = batch index z; operands advance by strideA/B/C elements per z; the LAST batch element may
 //                have fewer rows (M_last) and a shorter K (K_last) — the clipped bottom block of a wavefront of reflector blocks
 //
-// (32 WMI)x128x8 tile per 256-thread workgroup (4 waves as 2x2, each WMI x 4 MFMA tiles of 16x16; WMI = 4: 128 rows, WMI = 2:
-// 64 rows for outputs with M <= 64), LDS tiles kept K-major ([k][m], [k][n]) so a wave's operand read is 16 consecutive doubles
+//   symA       : (TA = false) A is symmetric and only its LOWER triangle (plus the full 128 x 128 diagonal tiles) holds valid data:
+//                k-chunks right of a row tile's diagonal tile are read transposed, A[row][k] = A[k][row]
+//
+// (32 WMI)x(32 WNI)x8 tile per 256-thread workgroup (4 waves as 2x2, each WMI x WNI MFMA tiles of 16x16; 4: 128 rows / columns,
+// 2: 64 for outputs with M <= 64 / N <= 64), LDS tiles kept K-major ([k][m], [k][n]) so a wave's operand read is 16 consecutive doubles
 // per k-row; rows padded by 16 doubles so the four k-rows a ds_read_b64 touches fall on disjoint bank halves.  f64 MFMA lane maps:
 // A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], C/D col = l&15, row = (l>>4) + 4*reg.
 #pragma once
@@ -24,7 +27,7 @@ typedef double doublex4 __attribute__((ext_vector_type(4)));
 #ifndef PG_DBK
 #define PG_DBK 8
 #endif
-constexpr int DBN = 128, DBK = PG_DBK, DPAD = 16, DPASS = DBK / 8;   // staging works in passes of 8 k-rows
+constexpr int DBK = PG_DBK, DPAD = 16, DPASS = DBK / 8;   // staging works in passes of 8 k-rows
 
 struct DgemmParams {
     long long M, N, K, lda, ldb, ldc;
@@ -41,12 +44,13 @@ struct DgemmParams {
     int nbatch;                             // >= 1
     long long strideA, strideB, strideC;    // elements per batch index
     long long M_last, K_last;               // dimensions of batch element nbatch - 1 (0: same as M / K)
+    int symA;                               // TA = false only; needs 128-row tiles (WMI = 4) and lda = row stride of the symmetric matrix
 };
 
-template <bool TA, bool TB, int WMI>
+template <bool TA, bool TB, int WMI, int WNI, bool SYM>
 __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
 {
-    constexpr int DBM = 32 * WMI;
+    constexpr int DBM = 32 * WMI, DBN = 32 * WNI;
     __shared__ double As[2][DBK][DBM + DPAD];
     __shared__ double Bs[2][DBK][DBN + DPAD];
     const int z = blockIdx.z;
@@ -62,11 +66,11 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
 
-    doublex4 acc[WMI][4];
+    doublex4 acc[WMI][WNI];
 #pragma unroll
     for (int i = 0; i < WMI; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < WNI; j++)
 #pragma unroll
             for (int e = 0; e < 4; e++) acc[i][j][e] = 0.0;
 
@@ -87,21 +91,35 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
             if (TB) {
                 // B tile: 128 rows (n) x 8 (k): thread -> row tid/2, 4 consecutive k (k index XOR-ed as a block of 4)
                 const long long row = n0 + (tid >> 1), kc = k0 + (tid & 1) * 4, kp = kc ^ (long long)gp.kxorB;
-                if (fastB && kc + 3 < KEND) load4d(Bp + row * gp.ldb + kp, rb[ps]);
-                else {
+                if (DBN == 128 || (tid >> 1) < DBN) {
+                    if (fastB && kc + 3 < KEND) load4d(Bp + row * gp.ldb + kp, rb[ps]);
+                    else {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) rb[ps][q] = (row < gp.N && kc + q < KEND) ? Bp[row * gp.ldb + kp + q] : 0.0;
+                        for (int q = 0; q < 4; q++) rb[ps][q] = (row < gp.N && kc + q < KEND) ? Bp[row * gp.ldb + kp + q] : 0.0;
+                    }
                 }
             } else {
                 // B tile: 8 rows (k) x 128 cols: thread -> row tid/32, 4 consecutive cols
                 const long long kr = k0 + (tid >> 5), col = n0 + (tid & 31) * 4;
-                if (fastB && kr < KEND) load4d(Bp + kr * gp.ldb + col, rb[ps]);
-                else {
+                if (DBN == 128 || (tid & 31) * 4 < DBN) {
+                    if (fastB && kr < KEND) load4d(Bp + kr * gp.ldb + col, rb[ps]);
+                    else {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) rb[ps][q] = (kr < KEND && col + q < gp.N) ? Bp[kr * gp.ldb + col + q] : 0.0;
+                        for (int q = 0; q < 4; q++) rb[ps][q] = (kr < KEND && col + q < gp.N) ? Bp[kr * gp.ldb + col + q] : 0.0;
+                    }
                 }
             }
             if (TA) {
+                const long long kr = k0 + (tid >> 5), col = m0 + (tid & 31) * 4;
+                if (DBM == 128 || (tid & 31) * 4 < DBM) {
+                    if (fastA && kr < KEND) load4d(Ap + kr * gp.lda + col, ra[ps]);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) ra[ps][q] = (kr < KEND && col + q < M) ? Ap[kr * gp.lda + col + q] : 0.0;
+                    }
+                }
+            } else if (SYM && k0 >= m0 + DBM) {
+                // symmetric A, k-chunk right of the diagonal tile: A[row][k] = A[k][row], read like a transposed operand
                 const long long kr = k0 + (tid >> 5), col = m0 + (tid & 31) * 4;
                 if ((tid & 31) * 4 < DBM) {
                     if (fastA && kr < KEND) load4d(Ap + kr * gp.lda + col, ra[ps]);
@@ -113,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
             } else {
                 // A tile: DBM rows (m) x 8 (k): thread -> row tid/2, 4 consecutive k
                 const long long row = m0 + (tid >> 1), kc = k0 + (tid & 1) * 4;
-                if ((tid >> 1) < DBM) {
+                if (DBM == 128 || (tid >> 1) < DBM) {
                     if (fastA && kc + 3 < KEND) load4d(Ap + row * gp.lda + kc, ra[ps]);
                     else {
 #pragma unroll
@@ -123,23 +141,27 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
             }
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, long long kbase) {
 #pragma unroll
         for (int ps = 0; ps < DPASS; ps++) {
             if (TB) {
+                if (DBN == 128 || (tid >> 1) < DBN) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) Bs[buf][8 * ps + (tid & 1) * 4 + q][tid >> 1] = rb[ps][q];
+                    for (int q = 0; q < 4; q++) Bs[buf][8 * ps + (tid & 1) * 4 + q][tid >> 1] = rb[ps][q];
+                }
             } else {
+                if (DBN == 128 || (tid & 31) * 4 < DBN) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) Bs[buf][8 * ps + (tid >> 5)][(tid & 31) * 4 + q] = rb[ps][q];
+                    for (int q = 0; q < 4; q++) Bs[buf][8 * ps + (tid >> 5)][(tid & 31) * 4 + q] = rb[ps][q];
+                }
             }
-            if (TA) {
-                if ((tid & 31) * 4 < DBM) {
+            if (TA || (SYM && kbase + 8 * ps >= m0 + DBM)) {
+                if (DBM == 128 || (tid & 31) * 4 < DBM) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) As[buf][8 * ps + (tid >> 5)][(tid & 31) * 4 + q] = ra[ps][q];
                 }
             } else {
-                if ((tid >> 1) < DBM) {
+                if (DBM == 128 || (tid >> 1) < DBM) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) As[buf][8 * ps + (tid & 1) * 4 + q][tid >> 1] = ra[ps][q];
                 }
@@ -150,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
     const int KT = (int)((KEND - kbeg + DBK - 1) / DBK);
     if (KT > 0) {
         gload(kbeg);
-        lstore(0);
+        lstore(0, kbeg);
     }
     __syncthreads();
     for (int kt = 0; kt < KT; kt++) {
@@ -159,24 +181,24 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
 #pragma unroll
         for (int kk = 0; kk < DBK; kk += 4) {
             const int kr = kk + (lane >> 4);
-            double a[WMI], b[4];
+            double a[WMI], b[WNI];
 #pragma unroll
             for (int i = 0; i < WMI; i++) a[i] = As[buf][kr][wm * (16 * WMI) + i * 16 + (lane & 15)];
 #pragma unroll
-            for (int j = 0; j < 4; j++) b[j] = Bs[buf][kr][wn * 64 + j * 16 + (lane & 15)];
+            for (int j = 0; j < WNI; j++) b[j] = Bs[buf][kr][wn * (16 * WNI) + j * 16 + (lane & 15)];
 #pragma unroll
             for (int i = 0; i < WMI; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WNI; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) lstore(buf ^ 1);
+        if (kt + 1 < KT) lstore(buf ^ 1, kbeg + (long long)(kt + 1) * DBK);
         __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < WMI; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const long long col = n0 + wn * 64 + j * 16 + (lane & 15);
+        for (int j = 0; j < WNI; j++) {
+            const long long col = n0 + wn * (16 * WNI) + j * 16 + (lane & 15);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const long long row = m0 + wm * (16 * WMI) + i * 16 + (lane >> 4) + 4 * e;
@@ -219,6 +241,7 @@ struct DgemmDesc {
     int nbatch = 1;
     long long strideA = 0, strideB = 0, strideC = 0, M_last = 0, K_last = 0;
     bool allow_splitk = true;
+    bool symA = false;
 };
 
 inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
@@ -232,9 +255,10 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
     gp.strideA = d.strideA; gp.strideB = d.strideB; gp.strideC = d.strideC; gp.M_last = d.M_last; gp.K_last = d.K_last;
     gp.vecA = ((uintptr_t)d.A % 16 == 0) && (d.lda % 2 == 0) && (d.strideA % 2 == 0);
     gp.vecB = ((uintptr_t)d.B % 16 == 0) && (d.ldb % 2 == 0) && (d.strideB % 2 == 0);
-    const bool small_m = d.M <= 64;
-    const int dbm = small_m ? 64 : 128;
-    const long long tiles = ((d.M + dbm - 1) / dbm) * ((d.N + DBN - 1) / DBN);
+    gp.symA = (d.symA && !d.transA) ? 1 : 0;
+    const bool small_m = d.M <= 64 && !d.symA, small_n = d.N <= 64 && !d.lower_only;
+    const int dbm = small_m ? 64 : 128, dbn = small_n ? 64 : 128;
+    const long long tiles = ((d.M + dbm - 1) / dbm) * ((d.N + dbn - 1) / dbn);
     // skinny output with a long K (V'V, V'Z of the back-transformation, the panel Grams): too few tiles to fill 256 CUs -> split K
     int ksplit = 1;
     if (d.allow_splitk && d.nbatch == 1 && tiles < 256 && d.K >= 1024) {
@@ -253,10 +277,15 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
     hipStream_t st = ctx->stream;
 #define PG_DG_LAUNCH(TA_, TB_)                                                               \
     do {                                                                                     \
-        if (small_m) dgemm_kernel<TA_, TB_, 2><<<grid, 256, 0, st>>>(gp);                    \
-        else dgemm_kernel<TA_, TB_, 4><<<grid, 256, 0, st>>>(gp);                            \
+        if (small_m && small_n) dgemm_kernel<TA_, TB_, 2, 2, false><<<grid, 256, 0, st>>>(gp);      \
+        else if (small_m) dgemm_kernel<TA_, TB_, 2, 4, false><<<grid, 256, 0, st>>>(gp);            \
+        else if (small_n) dgemm_kernel<TA_, TB_, 4, 2, false><<<grid, 256, 0, st>>>(gp);            \
+        else dgemm_kernel<TA_, TB_, 4, 4, false><<<grid, 256, 0, st>>>(gp);                         \
     } while (0)
-    if (d.transA && d.transB) PG_DG_LAUNCH(true, true);
+    if (gp.symA) {
+        if (small_n) dgemm_kernel<false, false, 4, 2, true><<<grid, 256, 0, st>>>(gp);
+        else dgemm_kernel<false, false, 4, 4, true><<<grid, 256, 0, st>>>(gp);
+    } else if (d.transA && d.transB) PG_DG_LAUNCH(true, true);
     else if (d.transA) PG_DG_LAUNCH(true, false);
     else if (d.transB) PG_DG_LAUNCH(false, true);
     else PG_DG_LAUNCH(false, false);

@@ -396,7 +396,7 @@ int sb2_alloc(int n, Sb2Work &w)
     const size_t nn = (size_t)n * n;
     int rc = PG_OK;
     struct { double **p; size_t cnt; } req[] = {
-        {&w.Vst, nn}, {&w.Tst, (size_t)(w.npan + 1) * B * B}, {&w.VW, ((size_t)n + 128) * 2 * B}, {&w.Qb, ((size_t)n + 128) * B}, {&w.sm, (size_t)16 * B * B},
+        {&w.Vst, nn}, {&w.Tst, (size_t)(w.npan + 1) * B * B}, {&w.VW, ((size_t)n + 384) * 2 * B}, {&w.Qb, ((size_t)n + 384) * B}, {&w.sm, (size_t)16 * B * B},
         {&w.S, ((size_t)n + 2) * SB_LD}, {&w.VV, nn}, {&w.TAU, (size_t)n * w.nk}, {&w.Vp, (size_t)w.ng * w.kmax * 128 * SB_G},
         {&w.Vtp, (size_t)w.ng * w.kmax * 128 * SB_G}, {&w.Wws, ((size_t)w.kmax + 1) * SB_G * n}, {&w.G, (size_t)BT1_BLOCK * BT1_BLOCK},
         {&w.T, (size_t)BT1_BLOCK * BT1_BLOCK}, {&w.W, (size_t)BT1_BLOCK * n}, {&w.W2, (size_t)BT1_BLOCK * n}};
@@ -430,6 +430,11 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
     PG_HIP(hipMemsetAsync(w.Vst, 0, (size_t)n * n * 8, st));
     PG_HIP(hipMemsetAsync(w.Tst, 0, (size_t)(w.npan + 1) * B * B * 8, st));
     PG_HIP(hipMemsetAsync(w.fail, 0, 4 * sizeof(int), st));
+    // The two big GEMMs of a panel work on 128 x 128 tiles aligned to multiples of 128 in A's own coordinates (only then do the
+    // fully updated diagonal tiles of one panel's rank-2b update coincide with the next panel's): every other panel their origin lies
+    // 64 rows above the trailing matrix, and [V W] is read with 64 zero rows in front (kept zero for the whole reduction).
+    PG_HIP(hipMemsetAsync(w.VW, 0, (size_t)128 * 2 * B * 8, st));
+    double *const VW0 = w.VW + (size_t)128 * 2 * B, *const Qb0 = w.Qb + (size_t)128 * B;
     double *sm = w.sm;
     auto SM = [&](int k) { return sm + (size_t)k * B * B; };
     const long long ld = n;
@@ -445,30 +450,36 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
             rc = dgemm(ctx, true, B, B, m, 1.0, P, ld, P, ld, 0.0, SM(SM_G1), B);
             if (rc) return rc;
             chol_inv_kernel<<<1, 64, 2 * MAT * 8, st>>>(SM(SM_G1), SM(SM_R1), SM(SM_R1INV), w.fail);
-            rc = dgemm(ctx, false, m, B, B, 1.0, P, ld, SM(SM_R1INV), B, 0.0, w.Qb, B);
-            if (!rc) rc = dgemm(ctx, true, B, B, m, 1.0, w.Qb, B, w.Qb, B, 0.0, SM(SM_G2), B);
+            rc = dgemm(ctx, false, m, B, B, 1.0, P, ld, SM(SM_R1INV), B, 0.0, Qb0, B);
+            if (!rc) rc = dgemm(ctx, true, B, B, m, 1.0, Qb0, B, Qb0, B, 0.0, SM(SM_G2), B);
             if (rc) return rc;
-            recon_kernel<<<1, 256, LDS4, st>>>(SM(SM_G2), SM(SM_R1), w.Qb, P, ld, w.VW, Vs, ld, Tp, SM(SM_XM), SM(SM_RPROD), w.fail);
+            recon_kernel<<<1, 256, LDS4, st>>>(SM(SM_G2), SM(SM_R1), Qb0, P, ld, VW0, Vs, ld, Tp, SM(SM_XM), SM(SM_RPROD), w.fail);
             // rows 64.. of V = Q1[64:, :] Xm  -> VW[:, 0:64]
-            rc = dgemm(ctx, false, m - B, B, B, 1.0, w.Qb + (size_t)B * B, B, SM(SM_XM), B, 0.0, w.VW + (size_t)B * 2 * B, 2 * B);
+            rc = dgemm(ctx, false, m - B, B, B, 1.0, Qb0 + (size_t)B * B, B, SM(SM_XM), B, 0.0, VW0 + (size_t)B * 2 * B, 2 * B);
             if (rc) return rc;
-            copy_v_kernel<<<(unsigned)(((m - B) * B + 255) / 256), 256, 0, st>>>(m, B, w.VW, Vs, ld);
+            copy_v_kernel<<<(unsigned)(((m - B) * B + 255) / 256), 256, 0, st>>>(m, B, VW0, Vs, ld);
         } else {
-            small_qr_kernel<<<1, 256, LDS4, st>>>((int)m, P, ld, w.VW, Vs, ld, Tp);
+            small_qr_kernel<<<1, 256, LDS4, st>>>((int)m, P, ld, VW0, Vs, ld, Tp);
         }
         PG_HIP(hipGetLastError());
         // two-sided update of A22 = A[j+64:, j+64:] (m x m):  Y = A22 V T,  W = Y - 1/2 V (T' (V' Y)),  A22 -= V W' + W V'
-        double *A22 = A + (size_t)(j + B) * ld + (j + B);
-        double *V = w.VW, *Wc = w.VW + B;                         // columns 0..63 / 64..127 of VW (ld 128)
-        rc = dgemm(ctx, false, m, B, m, 1.0, A22, ld, V, 2 * B, 0.0, w.Qb, B);                      // X  = A22 V
-        if (!rc) rc = dgemm(ctx, false, m, B, B, 1.0, w.Qb, B, Tp, B, 0.0, Wc, 2 * B);              // Y  = X T           -> W columns
+        const long long off = j + B, off_al = off & ~(long long)127, pad = off - off_al;      // pad = 0 or 64
+        double *A22al = A + (size_t)off_al * ld + off_al;
+        double *V = VW0, *Wc = VW0 + B;                           // columns 0..63 / 64..127 of VW (ld 128)
+        {   // X = A22 V: A22 symmetric with its lower triangle (+ diagonal tiles) valid
+            DgemmDesc d;
+            d.symA = true; d.M = m + pad; d.N = B; d.K = m + pad; d.alpha = 1.0; d.beta = 0.0;
+            d.A = A22al; d.lda = ld; d.B = VW0 - (size_t)pad * 2 * B; d.ldb = 2 * B; d.C = Qb0 - (size_t)pad * B; d.ldc = B;
+            rc = dgemm_ex(ctx, d);
+        }
+        if (!rc) rc = dgemm(ctx, false, m, B, B, 1.0, Qb0, B, Tp, B, 0.0, Wc, 2 * B);               // Y  = X T           -> W columns
         if (!rc) rc = dgemm(ctx, true, B, B, m, 1.0, V, 2 * B, Wc, 2 * B, 0.0, SM(SM_M1), B);       // M1 = V' Y
         if (!rc) rc = dgemm(ctx, true, B, B, B, -0.5, Tp, B, SM(SM_M1), B, 0.0, SM(SM_M2), B);      // M2 = -1/2 T' M1
         if (!rc) rc = dgemm(ctx, false, m, B, B, 1.0, V, 2 * B, SM(SM_M2), B, 1.0, Wc, 2 * B);      // W  = Y + V M2
         if (rc) return rc;
-        DgemmDesc d;                                                                               // A22 -= [V W] [W V]'
-        d.transB = true; d.kxorB = B; d.M = m; d.N = m; d.K = 2 * B; d.alpha = -1.0; d.beta = 1.0;
-        d.A = w.VW; d.lda = 2 * B; d.B = w.VW; d.ldb = 2 * B; d.C = A22; d.ldc = ld;
+        DgemmDesc d;                                                                               // A22 -= [V W] [W V]', lower triangle
+        d.transB = true; d.kxorB = B; d.M = m + pad; d.N = m + pad; d.K = 2 * B; d.alpha = -1.0; d.beta = 1.0; d.lower_only = true;
+        d.A = VW0 - (size_t)pad * 2 * B; d.lda = 2 * B; d.B = d.A; d.ldb = 2 * B; d.C = A22al; d.ldc = ld;
         rc = dgemm_ex(ctx, d);
         if (rc) return rc;
     }
