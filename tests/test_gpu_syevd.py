@@ -110,11 +110,16 @@ def test_stedc_divide_and_conquer(name, ctx):
     assert np.abs(T @ Z - Z * ev).max() <= 5e-14 * scale * max(1, np.sqrt(n))
 
 
+@pytest.mark.parametrize("stages", ["1", "2"])
 @pytest.mark.parametrize("n", [1, 2, 7, 64, 129, 300, 1000, 1940])
-def test_syevd_invariants(n, ctx):
+def test_syevd_invariants(n, stages, ctx, monkeypatch):
     """pg_syevd_dev (SURVEY 8c Tier B): ||K - U L U'||_F/||K||_F <= 1e-12 sqrt(n), |U'U - I|_max <= 1e-12,
-    eigenvalues vs host LAPACK dsyevd within 1e-12 lambda_max; f32 outputs = clamp + cast of the f64 ones."""
+    eigenvalues vs host LAPACK dsyevd within 1e-12 lambda_max; f32 outputs = clamp + cast of the f64 ones.
+    Both reductions: one-stage Householder and two-stage (dense -> band -> tridiagonal; forced here, by default the size decides)."""
     from pygemma_amd import ops
+    if stages == "2" and n < 192:
+        pytest.skip("the two-stage path starts at n = 192")
+    monkeypatch.setenv("PG_SYEVD_STAGES", stages)
     K = _kin(n, seed=100 + n) if n > 2 else np.array([[2.0, 0], [0.5, 1.0]], np.float32)[:n, :n]
     K64 = np.tril(K.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
     ev32, U32, ev, U = ops.syevd(K, ctx=ctx, want64=True)
@@ -162,11 +167,14 @@ def _structured(name, n, rng):
 
 @pytest.mark.parametrize("name", ["rank_deficient", "block_diagonal", "identity_plus_tiny", "rank_one", "zero", "duplicated_samples",
                                   "diagonal", "huge_scale", "tiny_scale"])
-@pytest.mark.parametrize("n", [130, 601])
-def test_syevd_structured_matrices(name, n, ctx):
+@pytest.mark.parametrize("n,stages", [(130, "1"), (601, "1"), (601, "2"), (1153, "2")])
+def test_syevd_structured_matrices(name, n, stages, ctx, monkeypatch):
     """Degenerate spectra through the whole solver (Householder with zero columns, deflation-heavy merges, splits): same Tier-B
-    invariants on the float64 outputs; the scales 1e+-30 sit near the ends of the float32 range K arrives in."""
+    invariants on the float64 outputs; the scales 1e+-30 sit near the ends of the float32 range K arrives in.  Forced onto the
+    two-stage path these matrices are the ones whose panels CholeskyQR2 cannot factor (zero / dependent columns): the device
+    flag sends them to the one-stage reduction, and what comes back must satisfy the same invariants."""
     from pygemma_amd import ops
+    monkeypatch.setenv("PG_SYEVD_STAGES", stages)
     rng = np.random.default_rng(7 * n + len(name))
     K = _structured(name, n, rng).astype(np.float32)
     K64 = np.tril(K.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
@@ -180,3 +188,52 @@ def test_syevd_structured_matrices(name, n, ctx):
     res = np.linalg.norm(K64 - (U * ev) @ U.T) / max(np.linalg.norm(K64), 1e-300)
     assert res <= 1e-12 * np.sqrt(n)
     assert (ev32 >= 0).all() and np.isfinite(U32).all()
+
+
+@pytest.mark.parametrize("n", [192, 300, 777, 1300])
+def test_two_stage_pieces(n, ctx):
+    """The two stages of the tridiagonalisation one at a time (csrc/sb2.hip), against fp64 LAPACK:
+    stage 1: the band matrix keeps K's spectrum, Q1 (the back-transformation applied to I) is orthogonal and Q1 B Q1' = K, no panel
+             needed the fallback on a full-rank K;
+    stage 2: the tridiagonal keeps the band's spectrum, Q2 orthogonal, Q2 T Q2' = B, no wait of the bulge-chasing kernel expired."""
+    import scipy.linalg as sl
+    from pygemma_amd import _lib
+    L = _lib.load()
+    K = _kin(n, seed=3 * n)
+    K64 = np.tril(K.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
+    lam, nrm = np.linalg.eigvalsh(K64), np.abs(K64).max()
+    flags = (C.c_int * 4)()
+    dK, dA, dZ = ctx.to_device(K), ctx.alloc(n * n * 8), ctx.to_device(np.eye(n))
+    _lib.check(L.pgx_sb2_stage1_dev(ctx.handle, n, dK.ptr, dA.ptr, dZ.ptr, flags), "stage 1")
+    assert list(flags)[:2] == [0, 0]
+    A, Q1 = dA.download((n, n), np.float64), dZ.download((n, n), np.float64)
+    i, j = np.indices((n, n))
+    Bm = np.where((i >= j) & (i - j <= 64), A, 0.0)
+    Bm = Bm + np.tril(Bm, -1).T
+    assert np.abs(np.linalg.eigvalsh(Bm) - lam).max() <= 1e-12 * nrm
+    assert np.abs(Q1.T @ Q1 - np.eye(n)).max() <= 1e-13
+    assert np.abs(Q1 @ Bm @ Q1.T - K64).max() <= 1e-12 * nrm
+    dB, dd, de = ctx.to_device(Bm), ctx.alloc(n * 8), ctx.alloc(n * 8)
+    dZ.upload(np.eye(n))
+    _lib.check(L.pgx_sb2_stage2_dev(ctx.handle, n, dB.ptr, dd.ptr, de.ptr, dZ.ptr, flags), "stage 2")
+    assert list(flags)[:2] == [0, 0]
+    d, e, Q2 = dd.download((n,), np.float64), de.download((n,), np.float64)[: n - 1], dZ.download((n, n), np.float64)
+    T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    assert np.abs(sl.eigvalsh_tridiagonal(d, e) - lam).max() <= 1e-12 * nrm
+    assert np.abs(Q2.T @ Q2 - np.eye(n)).max() <= 1e-13
+    assert np.abs(Q2 @ T @ Q2.T - Bm).max() <= 1e-12 * nrm
+    for b in (dK, dA, dZ, dB, dd, de):
+        b.free()
+
+
+def test_two_stage_flags_a_rank_deficient_panel(ctx):
+    """A K whose first panel has dependent columns: stage 1 must raise its flag (pg_syevd_dev then takes the one-stage path)."""
+    from pygemma_amd import _lib
+    L = _lib.load()
+    n = 400
+    K = np.ones((n, n), np.float32)
+    flags = (C.c_int * 4)()
+    dK, dA = ctx.to_device(K), ctx.alloc(n * n * 8)
+    _lib.check(L.pgx_sb2_stage1_dev(ctx.handle, n, dK.ptr, dA.ptr, None, flags), "stage 1")
+    assert flags[0] != 0
+    dK.free(); dA.free()
