@@ -255,6 +255,7 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
             packed = isinstance(X, PackedBed)
             x8 = (not packed) and X.dtype in (np.int8, np.uint8)
             x64 = (not packed) and X.dtype == np.float64
+            force_fp32 = os.environ.get("PYGEMMA_ROTATE", "") == "fp32" and not (packed or x8 or x64)
             esz = 1 if x8 else (8 if x64 else 4)
             pb_max, ldX = _batch_geometry(n, a, b)
             bpr = (n + 3) // 4
@@ -354,6 +355,8 @@ def _run_block(device, a, b, n, c, d, Wr, yr, X, dU, comm, grid, eigen, lrt, out
                                 elif x8:         # 8-bit block (always finite): genotype codes or split planes, chosen on the device
                                     _lib.check(L.pg_rotate_auto_i8_dev(ctx.handle, n, pb, dprep.ptr, dXc.ptr, int(X.dtype == np.uint8), ldX,
                                                                        dXr.ptr, ldx, dwork.ptr, None), "pg_rotate_auto_i8_dev")
+                                elif eigen and force_fp32:   # PYGEMMA_ROTATE=fp32: the reference-arithmetic kernel for every block (tests, A/B)
+                                    _lib.check(L.pg_rotate_dev(ctx.handle, n, pb, dU.ptr, n, dXc.ptr, ldX, dXr.ptr, ldx), "pg_rotate_dev")
                                 elif eigen:      # float32 block: path (genotype fp16x2 / split planes / fp32 MFMA) chosen on the device, no host wait
                                     _lib.check(L.pg_rotate_auto_dev(ctx.handle, n, pb, dU.ptr, n, dprep.ptr, dXc.ptr, ldX, dXr.ptr, ldx,
                                                                     dwork.ptr, None), "pg_rotate_auto_dev")
