@@ -113,6 +113,37 @@ def test_syevd_n10000_sampled_invariants(ctx):
     assert np.abs(U32.astype(np.float64) - U).max() <= 2.0 ** -24
 
 
+def test_syevd_n20000_sampled_fp64_invariants(ctx):
+    """Beyond the metric's size (the n >= 20 000 checks lived in a tool and at float32 level): the fp64 outputs of the
+    two-stage solver at n = 20 000 — residual on sampled eigenpairs, orthonormality of a sampled set, trace, ordering — at the
+    Tier-B gate 1e-12."""
+    from pygemma_amd import _lib
+    L = _lib.load()
+    n = 20000
+    rng = np.random.default_rng(20)
+    G = rng.standard_normal((n, n + 500), dtype=np.float32)
+    K = (G @ G.T) / np.float32(n + 500)
+    del G
+    dK, d64, U64 = ctx.to_device(K), ctx.alloc(n * 8), ctx.alloc(n * n * 8)
+    _lib.check(L.pg_syevd_dev(ctx.handle, n, dK.ptr, None, None, d64.ptr, U64.ptr), "pg_syevd_dev")
+    ev = d64.download((n,), np.float64)
+    idx = np.concatenate([[0, 1, n - 2, n - 1], rng.choice(n, 60, replace=False)])
+    cols = np.concatenate([idx, rng.choice(n, 192, replace=False)])
+    # only the sampled columns of U come back (n x n fp64 = 3.2 GB stays on the device)
+    Ufull = U64.download((n, n), np.float64)
+    V = Ufull[:, idx]
+    sub = Ufull[:, cols]
+    del Ufull
+    K64 = np.tril(K).astype(np.float64); K64 = K64 + np.tril(K64, -1).T
+    res = np.abs(K64 @ V - V * ev[idx][None, :]).max() / np.abs(ev).max()
+    assert res <= 1e-12, res
+    assert np.abs(sub.T @ sub - np.eye(sub.shape[1])).max() <= 1e-12
+    assert abs(ev.sum() - np.trace(K64)) <= 1e-10 * np.trace(K64)
+    assert (np.diff(ev) >= 0).all()
+    for b in (dK, d64, U64):
+        b.free()
+
+
 def test_kinship_n10000_sampled_entries_vs_float64():
     """N3 at the metric's size: K = Z Z'/p with p = 20 000 raw hard calls standardised on the device; sampled rows against float64."""
     from pygemma_amd import lmm

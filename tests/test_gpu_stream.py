@@ -83,14 +83,15 @@ def test_config5_n50000_eigen_false_grid_streamed_from_pinned(monkeypatch):
     np.testing.assert_allclose(df["p_wald"].to_numpy()[idx], orc["p_wald"], rtol=1e-9)
 
 
-def test_config5_n40000_rotation_from_host_eigenpairs(monkeypatch):
-    """BASELINE configs[4]'s rotation leg: precomputed eigenpairs (U = 6.4 GB float32 at n = 40 000) streamed from pinned host
-    memory, genotype rotation on the fp16 MFMA pipe at that size, association on top.  Checked: sampled rotated entries against
+def test_config5_n50000_rotation_from_host_eigenpairs(monkeypatch):
+    """BASELINE configs[4] as written, on one GPU: n = 50 000, grid path, precomputed eigenpairs (U = 10 GB float32) streamed from
+    pinned host memory through lmm.pygemma(eigenpairs=(d, U)), genotype rotation on the fp16 MFMA pipe at that size, association
+    on top.  Checked: sampled rotated entries against
     an fp64 dot product (error bound of tests/test_gpu_rotate.py), and the whole frame against the oracle fed with fp64-rotated
     columns (Tier C bar: the fp32-accumulation error class of the reference's own sgemm)."""
     from oracle import oracle as O
     from pygemma_amd import _lib, lmm
-    n, p, c = 40000, 1536, 2
+    n, p, c = 50000, 1536, 5
     monkeypatch.setattr(lmm, "_BATCH_SNPS", 512)
     rng = np.random.default_rng(40)
     U = lmm.pinned_empty((n, n), np.float32)
@@ -124,12 +125,11 @@ def test_config5_n40000_rotation_from_host_eigenpairs(monkeypatch):
     assert (Xr[:, n:] == 0).all()
     # (b) the pipeline from host eigenpairs
     st = {}
-    df = lmm.pygemma(Y, X, W, None, eigenpairs=(d, U), stats=st)
+    df = lmm.pygemma(Y, X, W, None, eigenpairs=(d, U), grid=True, stats=st)
     assert st["batches"] == 3 and np.isfinite(df["beta"].to_numpy()).all()
     idx = np.array([0, 1, 511, 512, 1023, 1024, p - 1])
-    U64 = U.astype(np.float64)
-    rot = lambda A: (U64.T @ A.astype(np.float64)).astype(np.float32)
-    truth = O.calculate(d, rot(Y), rot(W), rot(X[:, idx]), grid=False, order=0, nthreads=16)
+    rot = lambda A: np.concatenate([(U[:, r:r + 5000].astype(np.float64).T @ A.astype(np.float64)) for r in range(0, n, 5000)]).astype(np.float32)
+    truth = O.calculate(d, rot(Y), rot(W), rot(X[:, idx]), grid=True, order=0, nthreads=16)
     # (lambda itself is not compared: with this near-null phenotype most SNPs sit at the 1e-5 boundary where logL is flat)
     for col, tol in (("beta", 2e-3), ("se_beta", 1e-4)):
         np.testing.assert_allclose(df[col].to_numpy()[idx].astype(np.float64), truth[col].astype(np.float64), rtol=tol, atol=1e-7, err_msg=col)
