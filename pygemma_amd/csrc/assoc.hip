@@ -25,7 +25,17 @@
 namespace pg {
 
 constexpr int NLAM = 11;  // decade lambdas 10^-5 .. 10^5
-constexpr int WPB = 4;    // wavefronts (= SNPs) per workgroup
+#ifndef PG_ASSOC_WPB
+#define PG_ASSOC_WPB 2    // wavefronts (= SNPs) per workgroup
+#endif
+// Two wavefronts per workgroup (r3; it was 4).  A SNP whose Newton iteration runs to the reference's 100-step cap (pyx:1411) keeps its
+// whole workgroup's slots and LDS until it is done: in a 4-SNP workgroup three finished wavefronts idled behind each straggler.
+// Measured on one box, same inputs (weak-signal phenotype, 43 Newton evaluations per SNP on average, max 106 | default phenotype,
+// 6 evaluations for every SNP):   4 per workgroup 0.381 of the fp64 roof | 33.75 ms;   2: 0.464 | 33.8 ms;   1: 0.469 | 34.16 ms.
+// A persistent work queue inside the kernel (wavefronts pulling SNP indices from an atomic counter) reaches 0.479 on the weak-signal
+// phenotype too, but its loop costs registers (VGPR spills 58 -> 90 at c = 5) and 9 % on the default one: the hardware dispatcher
+// refilling small workgroups does the same job for free.
+constexpr int WPB = PG_ASSOC_WPB;
 #define PG_MINV 1e-35f    // pygemma_model.pyx:39
 // tuning knobs (overridable with -D for A/B builds)
 #ifndef PG_FUSE_PQ_MAX

@@ -132,53 +132,63 @@ template <class UC, class UD, class RH>
 __device__ __forceinline__ void solve_rows_wave(double *X, UC ucoef, UD urcp, RH rhs, int lane)
 {
     for (int j = 0; j < B; j++) {
-        double s0 = 0.0, s1 = 0.0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int k = 0;
-        for (; k + 1 < j; k += 2) {
-            s0 = fma(X[lane * P65 + k], ucoef(k, j), s0);
-            s1 = fma(X[lane * P65 + k + 1], ucoef(k + 1, j), s1);
+        for (; k + 4 <= j; k += 4) {          // four independent chains: eight LDS reads in flight
+            const double x0 = X[lane * P65 + k], x1 = X[lane * P65 + k + 1], x2 = X[lane * P65 + k + 2], x3 = X[lane * P65 + k + 3];
+            const double u0 = ucoef(k, j), u1 = ucoef(k + 1, j), u2 = ucoef(k + 2, j), u3 = ucoef(k + 3, j);
+            s0 = fma(x0, u0, s0); s1 = fma(x1, u1, s1); s2 = fma(x2, u2, s2); s3 = fma(x3, u3, s3);
         }
-        if (k < j) s0 = fma(X[lane * P65 + k], ucoef(k, j), s0);
-        X[lane * P65 + j] = (rhs(lane, j) - (s0 + s1)) * urcp(j);
+        for (; k < j; k++) s0 = fma(X[lane * P65 + k], ucoef(k, j), s0);
+        X[lane * P65 + j] = (rhs(lane, j) - ((s0 + s1) + (s2 + s3))) * urcp(j);
     }
 }
 
-// ---- pass 1 of CholeskyQR2: G -> R1 (upper) and R1^-1, one wavefront, no workgroup barriers --------------------------------
-// Row k of R from the rows above it (left-looking): lane j forms G[k][j] - sum_{i<k} R[i][k] R[i][j]; the pivot goes to every
-// lane through a scalar register.  Then X R = I row by row (solve_rows_wave).
+// ---- pass 1 of CholeskyQR2: G -> R1 (upper) and R1^-1, one wavefront, everything in registers -------------------------------
+// Lane j keeps column j of the matrix (64 doubles).  Right-looking Cholesky: at step k the pivot and the row R[k][i] reach every lane
+// through v_readlane (compile-time lane numbers: all loops are unrolled), no LDS, no barriers.  Then X R = I with lane i = row i of X,
+// the coefficient R[k][j] read from lane j's register k.  (The LDS version with run-time loops spent its time in LDS latency: 82 us;
+// the first, with workgroup barriers: 112 us.)
 __global__ __launch_bounds__(64) void chol_inv_kernel(const double *G, double *R, double *Rinv, int *fail)
 {
-    extern __shared__ double lds[];
-    double *A = lds, *X = lds + MAT;
-    __shared__ double rd[B];
     const int lane = threadIdx.x;
-    for (int i = 0; i < B; i++) A[i * P65 + lane] = G[i * B + lane];
-    wave_sync_lds();
+    double a[B], rc[B];
+#pragma unroll
+    for (int i = 0; i < B; i++) a[i] = G[i * B + lane];
     bool ok = true;
+#pragma unroll
     for (int k = 0; k < B; k++) {
-        double s0 = 0.0, s1 = 0.0;
-        int i = 0;
-        for (; i + 1 < k; i += 2) {
-            s0 = fma(A[i * P65 + k], A[i * P65 + lane], s0);
-            s1 = fma(A[(i + 1) * P65 + k], A[(i + 1) * P65 + lane], s1);
-        }
-        if (i < k) s0 = fma(A[i * P65 + k], A[i * P65 + lane], s0);
-        const double t = A[k * P65 + lane] - (s0 + s1);
-        const double tk = readlane_d(t, k);
-        const bool bad = !(tk > 0.0) || !(tk < 1.0e300);
+        const double akk = readlane_d(a[k], k);
+        const bool bad = !(akk > 0.0) || !(akk < 1.0e300);
         ok = ok && !bad;
-        const double d = bad ? 1.0 : sqrt(tk), rcp = 1.0 / d;
-        A[k * P65 + lane] = (lane == k) ? d : ((lane > k) ? t * rcp : 0.0);
-        if (lane == 0) rd[k] = rcp;
-        wave_sync_lds();
+        const double d = bad ? 1.0 : sqrt(akk), rcp = 1.0 / d;
+        rc[k] = rcp;
+        const double rk = (lane > k) ? a[k] * rcp : ((lane == k) ? d : 0.0);     // R[k][lane]
+        a[k] = rk;
+#pragma unroll
+        for (int i = k + 1; i < B; i++) a[i] = fma(-readlane_d(rk, i), rk, a[i]);   // A[i][lane] -= R[k][i] R[k][lane]  (used for lane >= i)
     }
     if (!ok && lane == 0) atomicOr(fail, 1);
-    solve_rows_wave(X, [&](int k, int j) { return A[k * P65 + j]; }, [&](int j) { return rd[j]; },
-                    [&](int i, int j) { return i == j ? 1.0 : 0.0; }, lane);
-    for (int i = 0; i < B; i++) {
-        R[i * B + lane] = A[i * P65 + lane];
-        Rinv[i * B + lane] = (lane >= i) ? X[i * P65 + lane] : 0.0;
+    // X R = I: lane = row i of X;  R[k][j] = lane j's a[k]
+    double x[B];
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < j; k++) {
+            if (k & 1) s1 = fma(x[k], readlane_d(a[k], j), s1);
+            else s0 = fma(x[k], readlane_d(a[k], j), s0);
+        }
+        x[j] = (((lane == j) ? 1.0 : 0.0) - (s0 + s1)) * rc[j];
     }
+#pragma unroll
+    for (int i = 0; i < B; i++) R[i * B + lane] = (lane >= i) ? a[i] : 0.0;
+    extern __shared__ double lds[];                      // transpose X through LDS for coalesced stores
+#pragma unroll
+    for (int j = 0; j < B; j++) lds[lane * P65 + j] = (j >= lane) ? x[j] : 0.0;
+    wave_sync_lds();
+#pragma unroll
+    for (int i = 0; i < B; i++) Rinv[i * B + lane] = lds[i * P65 + lane];
 }
 
 // ---- pass 2 + Householder reconstruction ------------------------------------------------------------------------------------
@@ -233,41 +243,31 @@ __global__ __launch_bounds__(256) void recon_kernel(const double *G2, const doub
     mm64([&](int a, int k) { return M0[a * P65 + k]; }, [&](int k, int b) { return M3[k * P65 + b]; },
          [&](int a, int b, double v) { Rprod[a * B + b] = v; }, tid);              // R2 R1 (scaled by D on the way out)
     __syncthreads();
-    // LU of E - Q D without pivoting on the top block, in place on M2 (Crout order, two wavefronts): after step k row k holds the
+    // LU of E - Q D without pivoting on the top block: ONE wavefront, the matrix in registers (lane j = column j), right-looking with
+    // compile-time lane numbers (v_readlane) — no LDS traffic, no barriers inside the 64 steps.  After step k row k holds the
     // eliminated entries W[k][j] = q~_j[k] of Q for j >= k (U[k][j] = -D_j W[k][j], U[k][k] = piv_k = 1 + |W[k][k]|), column k the
-    // multipliers L[r][k], r > k (= V's top block).  Wave 0: row k (lane = column); wave 1: column k (lane = row).
-    for (int k = 0; k < B; k++) {
-        double val = 0.0;
-        if (wave == 0) {
-            double s0 = 0.0, s1 = 0.0;
-            int t = 0;
-            for (; t + 1 < k; t += 2) {
-                s0 = fma(M2[k * P65 + t], M2[t * P65 + lane], s0);
-                s1 = fma(M2[k * P65 + t + 1], M2[(t + 1) * P65 + lane], s1);
-            }
-            if (t < k) s0 = fma(M2[k * P65 + t], M2[t * P65 + lane], s0);
-            val = M2[k * P65 + lane] - (s0 + s1);
-        } else if (wave == 1) {
-            double s0 = 0.0, s1 = 0.0;
-            int t = 0;
-            for (; t + 1 < k; t += 2) {
-                s0 = fma(M2[lane * P65 + t], M2[t * P65 + k], s0);
-                s1 = fma(M2[lane * P65 + t + 1], M2[(t + 1) * P65 + k], s1);
-            }
-            if (t < k) s0 = fma(M2[lane * P65 + t], M2[t * P65 + k], s0);
-            val = M2[lane * P65 + k] - (s0 + s1);
-        }
-        __syncthreads();                                   // all reads of this step done
-        if (wave == 0 && lane >= k) M2[k * P65 + lane] = val;
-        __syncthreads();
-        if (wave == 1) {
-            const double wkk = M2[k * P65 + k];
-            const double dk = (wkk >= 0.0) ? -1.0 : 1.0, pv = 1.0 - dk * wkk, rc = 1.0 / pv;
-            if (lane > k) M2[lane * P65 + k] = -dk * val * rc;
+    // multipliers L[r][k], r > k (= V's top block).  (Crout order on two wavefronts with three workgroup barriers per step: 222 us
+    // for the whole kernel; the first version, rank-one updates by the whole workgroup: 320.)
+    if (wave == 0) {
+        double m[B];
+#pragma unroll
+        for (int r = 0; r < B; r++) m[r] = M2[r * P65 + lane];
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            const double wkk = readlane_d(m[k], k);
+            const double dk = (wkk >= 0.0) ? -1.0 : 1.0, pv = 1.0 - dk * wkk, rc = 1.0 / pv, sc = -dk * rc;
             if (lane == 0) { Dg[k] = dk; piv[k] = pv; prc[k] = rc; }
+            const double mk = m[k];                              // W[k][lane]
+#pragma unroll
+            for (int r = k + 1; r < B; r++) {
+                const double l = readlane_d(m[r], k) * sc;       // L[r][k]
+                m[r] = (lane > k) ? fma(-l, mk, m[r]) : ((lane == k) ? l : m[r]);
+            }
         }
-        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < B; r++) M2[r * P65 + lane] = m[r];
     }
+    __syncthreads();
     // T = U Y1^-T: T Y1' = U, Y1' unit upper triangular with Y1'[k][j] = L[j][k]  (wave 0 -> M0);  Xm U = -R2^-1 D  (wave 1 -> M3)
     if (wave == 0)
         solve_rows_wave(M0, [&](int k, int j) { return M2[j * P65 + k]; }, [&](int) { return 1.0; },
