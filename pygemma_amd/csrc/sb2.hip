@@ -31,7 +31,10 @@ namespace pg {
 constexpr int B = SB_B;          // 64
 constexpr int P65 = B + 1;       // LDS pitch of a 64 x 64 matrix
 constexpr int MAT = B * P65;     // doubles per LDS matrix
-constexpr int BT1_BLOCK = 256;   // reflectors per block of the stage-1 back-transformation
+#ifndef PG_BT1_BLOCK
+#define PG_BT1_BLOCK 256
+#endif
+constexpr int BT1_BLOCK = PG_BT1_BLOCK;   // reflectors per block of the stage-1 back-transformation
 
 // small matrices in w.sm (b x b each)
 enum { SM_G1 = 0, SM_R1, SM_R1INV, SM_G2, SM_XM, SM_M1, SM_M2, SM_RPROD, SM_COUNT };
@@ -995,12 +998,13 @@ __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
     else store_rows(std::integral_constant<int, 1>{});
 }
 
-int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w)
+// the blocks (V, V T) of every (group, block index): needs only the reflectors, so the caller may run it on a second stream beside the
+// divide & conquer (st = nullptr: the context's stream)
+int bt2_prep_device(pg_ctx *ctx, int n, Sb2Work &w, hipStream_t st)
 {
     if (n < 3) return PG_OK;
-    hipStream_t st = ctx->stream;
-    constexpr int VR = 128, HGT = B + SB_G - 1;      // rows of a block
-    const int ng = w.ng, kmax = w.kmax;
+    if (!st) st = ctx->stream;
+    constexpr int VR = 128;
     const size_t lds = (size_t)(VR * P65 + 2 * MAT) * 8;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1008,8 +1012,18 @@ int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w)
         PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS_BYTES));
         attr_done = true;
     }
-    bt2_prep_kernel<<<dim3(ng, kmax), 256, lds, st>>>(n, w.nk, ng, w.VV, w.TAU, w.Vp, w.Vtp);
+    bt2_prep_kernel<<<dim3(w.ng, w.kmax), 256, lds, st>>>(n, w.nk, w.ng, w.VV, w.TAU, w.Vp, w.Vtp);
     PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w, bool prepared)
+{
+    if (n < 3) return PG_OK;
+    hipStream_t st = ctx->stream;
+    constexpr int VR = 128, HGT = B + SB_G - 1;      // rows of a block
+    const int ng = w.ng;
+    if (!prepared) { const int rc = bt2_prep_device(ctx, n, w, st); if (rc) return rc; }
     const size_t blk = (size_t)VR * SB_G;
     const int glast = ng - 1;
     const int nslab = (n + BT2_NS - 1) / BT2_NS;

@@ -35,7 +35,8 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w);
 // band of A -> compact storage -> bulge chasing: d (n), e (n - 1) on the device; reflectors in w.VV / w.TAU
 int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2Work &w);
 // Z (n x n row-major) <- Q2 Z, then Z <- Q1 Z
-int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w);
+int bt2_prep_device(pg_ctx *ctx, int n, Sb2Work &w, hipStream_t st);   // (V, V T) of every reflector block; st: stream to run on (nullptr: ctx's)
+int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w, bool prepared = false);
 int bt1_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w);
 void sb2_set_debug(int *host_mapped);   // debugging aid: see pgx_sb2_set_debug
 

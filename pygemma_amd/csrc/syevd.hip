@@ -1138,8 +1138,12 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
     StedcWork wk;
     double *A = nullptr, *dd = nullptr, *de = nullptr, *dev_ev = nullptr;
     int rc = PG_OK;
+    hipStream_t side_c = nullptr;       // set once the side stream exists (see below)
+    hipEvent_t ev_c = nullptr;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(st);
+        if (side_c) { (void)hipStreamSynchronize(side_c); (void)hipStreamDestroy(side_c); side_c = nullptr; }
+        if (ev_c) { (void)hipEventDestroy(ev_c); ev_c = nullptr; }
         for (double *p : {A, dd, de, dev_ev}) if (p) (void)hipFree(p);
         sb2_free(sw);
         stedc_free(wk);
@@ -1170,10 +1174,21 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
         cleanup();
         return PG_RETRY_ONESTAGE;
     }
+    // the reflector blocks of the second back-transformation need only the reflectors: built on a second stream beside the divide &
+    // conquer, whose many small, host-paced launches leave the chip mostly idle (11 ms at n = 10 000)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_prep = nullptr;
+    bool prepared = false;
+    if (!rc && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev_prep, hipEventDisableTiming) == hipSuccess) {
+        // (the stream has just been synchronised: the reflectors are complete)
+        if (bt2_prep_device(ctx, n, sw, side) == PG_OK && hipEventRecord(ev_prep, side) == hipSuccess) prepared = true;
+    }
+    side_c = side; ev_c = ev_prep;
     double *Z = nullptr;
     if (!rc) rc = stedc_device(ctx, n, hd.data(), he.data(), ev, wk, &Z);
     mark("divide&conquer");
-    if (!rc) rc = bt2_device(ctx, n, Z, sw);
+    if (prepared && hipStreamWaitEvent(st, ev_prep, 0) != hipSuccess) { (void)hipStreamSynchronize(side); }
+    if (!rc) rc = bt2_device(ctx, n, Z, sw, prepared);
     mark("back-transform 2");
     if (!rc) rc = bt1_device(ctx, n, Z, sw);
     mark("back-transform 1");
