@@ -3,8 +3,8 @@
 //
 //   C (MxN, row-major, ldc) = alpha * op(A) * op(B) + beta * C
 //   TA = false : A is M x K row-major (lda)            TA = true : A is stored K x M row-major (lda)
-//   TB = false : B is K x N row-major (ldb)            TB = true : B is stored N x K row-major (ldb); its k index may be
-//                                                                 XOR-ed with kxorB (a multiple of 4): [V W] read as [W V]
+//   TB = false : B is K x N row-major (ldb)            TB = true : B is stored N x K row-major (ldb)
+//   kxorB      : B's k index is XOR-ed with kxorB (a multiple of 8): the operand [V W] read as [W V]
 //   batch      : blockIdx.z = batch index z; operands advance by strideA/B/C elements per z; the LAST batch element may
 //                have fewer rows (M_last) and a shorter K (K_last) — the clipped bottom block of a wavefront of reflector blocks
 //
@@ -100,12 +100,12 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
                 }
             } else {
                 // B tile: 8 rows (k) x 128 cols: thread -> row tid/32, 4 consecutive cols
-                const long long kr = k0 + (tid >> 5), col = n0 + (tid & 31) * 4;
+                const long long kr = k0 + (tid >> 5), col = n0 + (tid & 31) * 4, kp = kr ^ (long long)gp.kxorB;
                 if (DBN == 128 || (tid & 31) * 4 < DBN) {
-                    if (fastB && kr < KEND) load4d(Bp + kr * gp.ldb + col, rb[ps]);
+                    if (fastB && kr < KEND) load4d(Bp + kp * gp.ldb + col, rb[ps]);
                     else {
 #pragma unroll
-                        for (int q = 0; q < 4; q++) rb[ps][q] = (kr < KEND && col + q < gp.N) ? Bp[kr * gp.ldb + col + q] : 0.0;
+                        for (int q = 0; q < 4; q++) rb[ps][q] = (kr < KEND && col + q < gp.N) ? Bp[kp * gp.ldb + col + q] : 0.0;
                     }
                 }
             }
@@ -251,7 +251,7 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
     gp.M = d.M; gp.N = d.N; gp.K = d.K; gp.lda = d.lda; gp.ldb = d.ldb; gp.ldc = d.ldc;
     gp.A = d.A; gp.B = d.B; gp.C = d.C; gp.alpha = d.alpha; gp.beta = d.beta;
     gp.lower = d.lower_only ? 1 : 0; gp.ksplit = 1; gp.kchunk = d.K; gp.ws = nullptr;
-    gp.kxorB = d.transB ? d.kxorB : 0; gp.nbatch = d.nbatch;
+    gp.kxorB = d.kxorB; gp.nbatch = d.nbatch;
     gp.strideA = d.strideA; gp.strideB = d.strideB; gp.strideC = d.strideC; gp.M_last = d.M_last; gp.K_last = d.K_last;
     gp.vecA = ((uintptr_t)d.A % 16 == 0) && (d.lda % 2 == 0) && (d.strideA % 2 == 0);
     gp.vecB = ((uintptr_t)d.B % 16 == 0) && (d.ldb % 2 == 0) && (d.strideB % 2 == 0);

@@ -155,6 +155,7 @@ __device__ __forceinline__ void solve_rows_wave(double *X, UC ucoef, UD urcp, RH
 __global__ __launch_bounds__(64) void chol_inv_kernel(const double *G, double *R, double *Rinv, int *fail)
 {
     const int lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);     // runs beside the trailing update's MFMA waves (look-ahead): a latency chain, served first
     double a[B], rc[B];
 #pragma unroll
     for (int i = 0; i < B; i++) a[i] = G[i * B + lane];
@@ -203,8 +204,11 @@ __global__ __launch_bounds__(64) void chol_inv_kernel(const double *G, double *R
 __global__ __launch_bounds__(256) void recon_kernel(const double *G2, const double *R1g, const double *Q1top, double *Aband, long long lda,
                                                     double *VW, double *Vst, long long ldv, double *Tout, double *Xm, double *Rprod, int *fail)
 {
+    // three LDS matrices (100 KB: the kernel has to find room on a CU beside the workgroups of the trailing update it overlaps):
+    // M0: G2 -> R2 -> T;   M1: R2^-1 -> Xm (in place);   M2: R1 -> top block of Q -> its LU
     extern __shared__ double lds[];
-    double *M0 = lds, *M1 = lds + MAT, *M2 = lds + 2 * MAT, *M3 = lds + 3 * MAT;
+    __builtin_amdgcn_s_setprio(3);     // runs beside the trailing update's MFMA waves (look-ahead): a latency chain, served first
+    double *M0 = lds, *M1 = lds + MAT, *M2 = lds + 2 * MAT;
     __shared__ double Dg[B], piv[B], prc[B];
     __shared__ double red[4];
     const int tid = threadIdx.x, i = tid >> 2, j0 = (tid & 3) * 16, lane = tid & 63, wave = tid >> 6;
@@ -219,13 +223,12 @@ __global__ __launch_bounds__(256) void recon_kernel(const double *G2, const doub
     }
     for (int s = 1; s < 64; s <<= 1) { const double o = __shfl_xor(err, s, 64); err = (o > err || !(o == o)) ? o : err; }
     if (lane == 0) red[wave] = err;
-    load64(M3, R1g, B, tid);                                                      // M3 = R1
+    load64(M2, R1g, B, tid);                                                      // M2 = R1
     __syncthreads();
     double e_all = red[0];
     for (int w = 1; w < 4; w++) e_all = (red[w] > e_all || !(red[w] == red[w])) ? red[w] : e_all;
     if (tid == 0 && !(e_all <= 0.05)) atomicOr(fail, 1);
     if (e_all < 1.0e-8) {
-        __syncthreads();
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int c = j0 + q;
@@ -241,10 +244,11 @@ __global__ __launch_bounds__(256) void recon_kernel(const double *G2, const doub
         solve_right_upper64(M1, [&](int k, int j) { return M0[k * P65 + j]; }, [&](int j) { return M0[j * P65 + j]; },
                             [&](int a, int b) { return a == b ? 1.0 : 0.0; }, tid);   // M1 = R2^-1
     }
+    mm64([&](int a, int k) { return M0[a * P65 + k]; }, [&](int k, int b) { return M2[k * P65 + b]; },
+         [&](int a, int b, double v) { Rprod[a * B + b] = v; }, tid);              // R2 R1 (scaled by D on the way out)
+    __syncthreads();                                                              // R1 is done with: M2 takes the top block of Q
     mm64([&](int a, int k) { return Q1top[a * B + k]; }, [&](int k, int b) { return M1[k * P65 + b]; },
          [&](int a, int b, double v) { M2[a * P65 + b] = v; }, tid);               // M2 = top block of Q = Q1 R2^-1
-    mm64([&](int a, int k) { return M0[a * P65 + k]; }, [&](int k, int b) { return M3[k * P65 + b]; },
-         [&](int a, int b, double v) { Rprod[a * B + b] = v; }, tid);              // R2 R1 (scaled by D on the way out)
     __syncthreads();
     // LU of E - Q D without pivoting on the top block: ONE wavefront, the matrix in registers (lane j = column j), right-looking with
     // compile-time lane numbers (v_readlane) — no LDS traffic, no barriers inside the 64 steps.  After step k row k holds the
@@ -271,19 +275,19 @@ __global__ __launch_bounds__(256) void recon_kernel(const double *G2, const doub
         for (int r = 0; r < B; r++) M2[r * P65 + lane] = m[r];
     }
     __syncthreads();
-    // T = U Y1^-T: T Y1' = U, Y1' unit upper triangular with Y1'[k][j] = L[j][k]  (wave 0 -> M0);  Xm U = -R2^-1 D  (wave 1 -> M3)
+    // T = U Y1^-T: T Y1' = U, Y1' unit upper triangular with Y1'[k][j] = L[j][k]  (wave 0 -> M0);  Xm U = -R2^-1 D  (wave 1, in place on M1)
     if (wave == 0)
         solve_rows_wave(M0, [&](int k, int j) { return M2[j * P65 + k]; }, [&](int) { return 1.0; },
                         [&](int a, int b) { return (a == b) ? piv[b] : ((a < b) ? -Dg[b] * M2[a * P65 + b] : 0.0); }, lane);
-    else if (wave == 1)
-        solve_rows_wave(M3, [&](int k, int j) { return -Dg[j] * M2[k * P65 + j]; }, [&](int j) { return prc[j]; },
+    else if (wave == 1)      // in place on M1: a lane reads the right-hand side of its own row at (a, b) just before it writes X[a][b] there
+        solve_rows_wave(M1, [&](int k, int j) { return -Dg[j] * M2[k * P65 + j]; }, [&](int j) { return prc[j]; },
                         [&](int a, int b) { return -M1[a * P65 + b] * Dg[b]; }, lane);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int c = j0 + q;
         Tout[i * B + c] = M0[i * P65 + c];
-        Xm[i * B + c] = M3[i * P65 + c];
+        Xm[i * B + c] = M1[i * P65 + c];
         const double v = (i == c) ? 1.0 : ((i > c) ? M2[i * P65 + c] : 0.0);
         VW[(long long)i * (2 * B) + c] = v;
         Vst[(long long)i * ldv + c] = v;
@@ -363,6 +367,19 @@ __global__ __launch_bounds__(256) void small_qr_kernel(int m, double *P, long lo
     }
 }
 
+// [V W] (m x 128 row-major) -> its transpose (128 x ldt row-major, columns c0 ..): both operands of the rank-128 update k-major, so
+// that dgemm's loads walk along m with 16-byte accesses (with k contiguous per row the update ran at 0.30 MFMA-busy)
+__global__ __launch_bounds__(256) void transpose_vw_kernel(long long m, const double *VW, double *VWt, long long ldt)
+{
+    __shared__ double tile[64][65];
+    const long long r0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = (r0 + r < m) ? VW[(r0 + r) * (2 * B) + c0 + tx] : 0.0;
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4)
+        if (r0 + tx < m) VWt[(long long)(c0 + c) * ldt + r0 + tx] = tile[tx][c];
+}
+
 // rows [r_begin, m) of the panel's V (VW columns 0..63) into the reflector store
 __global__ void copy_v_kernel(long long m, long long r_begin, const double *VW, double *Vst, long long ldv)
 {
@@ -427,7 +444,7 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
     if (!attr_done) {
         PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recon_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
         PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
-        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAT * 8));
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MAT * 8));
         attr_done = true;
     }
     PG_HIP(hipMemsetAsync(w.Vst, 0, (size_t)n * n * 8, st));
@@ -438,11 +455,17 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
     // 64 rows above the trailing matrix, and [V W] is read with 64 zero rows in front (kept zero for the whole reduction).
     PG_HIP(hipMemsetAsync(w.VW, 0, (size_t)128 * 2 * B * 8, st));
     double *const VW0 = w.VW + (size_t)128 * 2 * B, *const Qb0 = w.Qb + (size_t)128 * B;
+    // transposed copy of [V W] for the rank-128 update (the back-transformation's work space is free during stage 1): 128 rows of
+    // ldt doubles, the panel's rows from column 128 on, the 128 columns in front kept zero
+    const long long ldt = ((long long)n + 128 + 127) / 128 * 128;
+    double *const VWt = w.Wws;
+    PG_HIP(hipMemsetAsync(VWt, 0, (size_t)128 * ldt * 8, st));
     double *sm = w.sm;
     auto SM = [&](int k) { return sm + (size_t)k * B * B; };
     const long long ld = n;
-    int pan = 0;
-    for (int j = 0; n - j - B >= 2; j += B, pan++) {
+    // factorisation of the panel at column j (everything that needs only the panel's own columns): on the stream of context c
+    auto factor = [&](pg_ctx *c, int j, int pan) -> int {
+        hipStream_t cs = c->stream;
         const long long m = n - j - B;
         double *P = A + (size_t)(j + B) * ld + j;                 // m x 64 panel below the diagonal block
         double *Vs = w.Vst + (size_t)(j + B) * ld + j;
@@ -450,21 +473,57 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
         int rc = PG_OK;
         if (m > B) {
             // CholeskyQR2: G1 = P'P, R1; Q1 = P R1^-1; G2 = Q1'Q1, R2; (Q = Q1 R2^-1 only through its top block and Xm)
-            rc = dgemm(ctx, true, B, B, m, 1.0, P, ld, P, ld, 0.0, SM(SM_G1), B);
+            rc = dgemm(c, true, B, B, m, 1.0, P, ld, P, ld, 0.0, SM(SM_G1), B);
             if (rc) return rc;
-            chol_inv_kernel<<<1, 64, 2 * MAT * 8, st>>>(SM(SM_G1), SM(SM_R1), SM(SM_R1INV), w.fail);
-            rc = dgemm(ctx, false, m, B, B, 1.0, P, ld, SM(SM_R1INV), B, 0.0, Qb0, B);
-            if (!rc) rc = dgemm(ctx, true, B, B, m, 1.0, Qb0, B, Qb0, B, 0.0, SM(SM_G2), B);
+            chol_inv_kernel<<<1, 64, MAT * 8, cs>>>(SM(SM_G1), SM(SM_R1), SM(SM_R1INV), w.fail);
+            rc = dgemm(c, false, m, B, B, 1.0, P, ld, SM(SM_R1INV), B, 0.0, Qb0, B);
+            if (!rc) rc = dgemm(c, true, B, B, m, 1.0, Qb0, B, Qb0, B, 0.0, SM(SM_G2), B);
             if (rc) return rc;
-            recon_kernel<<<1, 256, LDS4, st>>>(SM(SM_G2), SM(SM_R1), Qb0, P, ld, VW0, Vs, ld, Tp, SM(SM_XM), SM(SM_RPROD), w.fail);
+            recon_kernel<<<1, 256, 3 * MAT * 8, cs>>>(SM(SM_G2), SM(SM_R1), Qb0, P, ld, VW0, Vs, ld, Tp, SM(SM_XM), SM(SM_RPROD), w.fail);
             // rows 64.. of V = Q1[64:, :] Xm  -> VW[:, 0:64]
-            rc = dgemm(ctx, false, m - B, B, B, 1.0, Qb0 + (size_t)B * B, B, SM(SM_XM), B, 0.0, VW0 + (size_t)B * 2 * B, 2 * B);
+            rc = dgemm(c, false, m - B, B, B, 1.0, Qb0 + (size_t)B * B, B, SM(SM_XM), B, 0.0, VW0 + (size_t)B * 2 * B, 2 * B);
             if (rc) return rc;
-            copy_v_kernel<<<(unsigned)(((m - B) * B + 255) / 256), 256, 0, st>>>(m, B, VW0, Vs, ld);
+            copy_v_kernel<<<(unsigned)(((m - B) * B + 255) / 256), 256, 0, cs>>>(m, B, VW0, Vs, ld);
         } else {
-            small_qr_kernel<<<1, 256, LDS4, st>>>((int)m, P, ld, VW0, Vs, ld, Tp);
+            small_qr_kernel<<<1, 256, LDS4, cs>>>((int)m, P, ld, VW0, Vs, ld, Tp);
         }
         PG_HIP(hipGetLastError());
+        return PG_OK;
+    };
+    // Look-ahead (opt-in: PG_SB2_LOOKAHEAD=1): the rank-128 update of panel j is issued as its first tile column (which holds the next
+    // panel) and the rest; the next panel's factorisation — a chain of single-workgroup kernels and small GEMMs, ~250 us of mostly idle
+    // chip — runs on a second, high-priority stream beside the rest.  [V W] is read by the update from its transposed copy, so the
+    // factorisation may overwrite V, Q and the small matrices at once; it has its own split-K work space (the context copy below).
+    // Measured at n = 10 000: the two do run side by side (kernel trace), but the latency chain slows down by what it hides — its single
+    // wavefronts share SIMDs with the update's MFMA waves: Cholesky 61 -> 145 us, reconstruction 182 -> 205 us, with or without
+    // s_setprio — and the phase stays at 116 ms (118.7 without).  Off by default: one stream, nothing to go wrong.
+    pg_ctx side = *ctx;
+    side.scratch = nullptr; side.scratch_bytes = 0; side.stream = nullptr;
+    hipEvent_t e_col = nullptr, e_fac = nullptr;
+    int prio_lo = 0, prio_hi = 0;
+    bool ahead = false;
+    if (getenv("PG_SB2_LOOKAHEAD")) {
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // the factorisation's small workgroups take freed CU slots first
+        ahead = hipStreamCreateWithPriority(&side.stream, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+                hipEventCreateWithFlags(&e_col, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e_fac, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!getenv("PG_SB2_LOOKAHEAD")) ahead = false;
+    auto finish = [&](int rc) {
+        if (side.stream) { (void)hipStreamSynchronize(side.stream); (void)hipStreamDestroy(side.stream); }
+        if (e_col) (void)hipEventDestroy(e_col);
+        if (e_fac) (void)hipEventDestroy(e_fac);
+        if (side.scratch) (void)hipFree(side.scratch);
+        return rc;
+    };
+    int pan = 0;
+    bool factored = false;          // the current panel's factorisation has been issued (by the previous iteration's look-ahead)
+    for (int j = 0; n - j - B >= 2; j += B, pan++) {
+        const long long m = n - j - B;
+        double *Tp = w.Tst + (size_t)pan * B * B;
+        int rc = PG_OK;
+        if (!factored) rc = factor(ctx, j, pan);
+        else if (hipStreamWaitEvent(st, e_fac, 0) != hipSuccess) rc = PG_EHIP;
+        if (rc) return finish(rc);
         // two-sided update of A22 = A[j+64:, j+64:] (m x m):  Y = A22 V T,  W = Y - 1/2 V (T' (V' Y)),  A22 -= V W' + W V'
         const long long off = j + B, off_al = off & ~(long long)127, pad = off - off_al;      // pad = 0 or 64
         double *A22al = A + (size_t)off_al * ld + off_al;
@@ -479,14 +538,35 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
         if (!rc) rc = dgemm(ctx, true, B, B, m, 1.0, V, 2 * B, Wc, 2 * B, 0.0, SM(SM_M1), B);       // M1 = V' Y
         if (!rc) rc = dgemm(ctx, true, B, B, B, -0.5, Tp, B, SM(SM_M1), B, 0.0, SM(SM_M2), B);      // M2 = -1/2 T' M1
         if (!rc) rc = dgemm(ctx, false, m, B, B, 1.0, V, 2 * B, SM(SM_M2), B, 1.0, Wc, 2 * B);      // W  = Y + V M2
-        if (rc) return rc;
-        DgemmDesc d;                                                                               // A22 -= [V W] [W V]', lower triangle
-        d.transB = true; d.kxorB = B; d.M = m + pad; d.N = m + pad; d.K = 2 * B; d.alpha = -1.0; d.beta = 1.0; d.lower_only = true;
-        d.A = VW0 - (size_t)pad * 2 * B; d.lda = 2 * B; d.B = d.A; d.ldb = 2 * B; d.C = A22al; d.ldc = ld;
+        if (rc) return finish(rc);
+        transpose_vw_kernel<<<dim3((unsigned)((m + 63) / 64), 2), 256, 0, st>>>(m, VW0, VWt + 128, ldt);
+        if (hipGetLastError() != hipSuccess) return finish(PG_EHIP);
+        // A22 -= [V W] [W V]' on the lower triangle: first tile column, then (beside the next panel's factorisation) the rest
+        const long long mm = m + pad;
+        const bool next = n - (j + B) - B >= 2;
+        DgemmDesc d;
+        d.transA = true; d.kxorB = B; d.K = 2 * B; d.alpha = -1.0; d.beta = 1.0; d.lower_only = true; d.lda = ldt; d.ldb = ldt; d.ldc = ld;
+        const bool split = ahead && next && mm > 128;
+        d.M = mm; d.N = split ? 128 : mm;
+        d.A = VWt + 128 - pad; d.B = d.A; d.C = A22al;
         rc = dgemm_ex(ctx, d);
-        if (rc) return rc;
+        if (rc) return finish(rc);
+        factored = false;
+        if (split) {
+            // host order matters: the rest of the update is enqueued first (the chip must have it to run beside the factorisation)
+            if (hipEventRecord(e_col, st) != hipSuccess) return finish(PG_EHIP);
+            d.M = mm - 128; d.N = mm - 128;
+            d.A = VWt + 128 - pad + 128; d.B = d.A; d.C = A22al + (size_t)128 * ld + 128;
+            rc = dgemm_ex(ctx, d);
+            if (rc) return finish(rc);
+            if (hipStreamWaitEvent(side.stream, e_col, 0) != hipSuccess) return finish(PG_EHIP);
+            rc = factor(&side, j + B, pan + 1);
+            if (rc) return finish(rc);
+            if (hipEventRecord(e_fac, side.stream) != hipSuccess) return finish(PG_EHIP);
+            factored = true;
+        }
     }
-    return PG_OK;
+    return finish(PG_OK);
 }
 
 // ---- band storage ---------------------------------------------------------------------------------------------------------------
