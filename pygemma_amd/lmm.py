@@ -171,6 +171,19 @@ class _Prefetch:
         self.ctxs, self.plans = [], []
         self.bytes = 0
         self.stop = False                        # set when the eigensolver is done: the batch in flight is the last one
+        self.threads = []
+        try:
+            self._plan(blocks, n, esz)
+        except BaseException:                    # a context or buffer of GPU g failed: release those of the GPUs before it
+            for ctx in self.ctxs:
+                ctx.close()
+            self.ctxs = []
+            raise
+        self.threads = [threading.Thread(target=self._run, args=(g,)) for g in range(len(blocks))]
+        for th in self.threads:
+            th.start()
+
+    def _plan(self, blocks, n, esz):
         for g, (a, b) in enumerate(blocks):
             ctx = _lib.Context(g)
             self.ctxs.append(ctx)
@@ -183,9 +196,6 @@ class _Prefetch:
             batches = batches[: max(0, int(budget // per))]
             big = ctx.alloc(per * len(batches)) if batches else None
             self.plans.append((batches, big, per, ldX))
-        self.threads = [threading.Thread(target=self._run, args=(g,)) for g in range(len(blocks))]
-        for th in self.threads:
-            th.start()
 
     def _run(self, g):
         try:
@@ -527,161 +537,179 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     t0 = time.time()
     ectx = dU0 = None  # the eigensolver's context on GPU 0 and U resident there (reused by GPU 0's SNP loop)
     xpin = pre = None
-    if eigen and eigenpairs is None and not packed and not checkpoint and X.flags.c_contiguous and _PREFETCH_MAX > 0:
-        # the eigensolver leaves PCIe idle for ~0.6 s at n = 10 000 (52 s at 50 000): X starts moving now
-        try:
-            if _lib.is_pinned(X):
-                pre = _Prefetch(L, X, blocks, n, X.dtype.itemsize, verbose)
-        except _lib.PgError as ex:
-            _log(verbose, f"prefetch not started ({ex})")
-    if eigen:
-        ectx = _lib.Context(0)
-        try:
-            if eigenpairs is not None:
-                ev, Uh = eigenpairs
-                Uh = np.asarray(Uh)
-                if Uh.shape != (n, n):
-                    raise ValueError(f"eigenpairs: U must be ({n},{n}), got {Uh.shape}")
-                if Uh.dtype != np.float32 or not Uh.flags.c_contiguous:
-                    Uh = np.ascontiguousarray(Uh, np.float32)                       # lmm.py:154
-                eigenVals = np.maximum(0.0, np.asarray(ev)).astype(np.float32).reshape(-1)   # lmm.py:157-160
-                if eigenVals.shape[0] != n:
-                    raise ValueError(f"eigenpairs: {n} eigenvalues expected, got {eigenVals.shape}")
-                dU0 = ectx.alloc(n * n * 4)
-                if _lib.is_pinned(Uh):     # one DMA straight out of the caller's pinned array
-                    _lib.check(L.pg_memcpy_h2d_async(ectx.handle, dU0.ptr, Uh.ctypes.data, Uh.nbytes), "pg_memcpy_h2d_async")
-                    ectx.sync()
-                else:                      # pageable: row panels through a pinned double buffer, copy threads ahead of the DMA
-                    rows = max(1, min(n, (256 << 20) // (n * 4)))
-                    stg = _Staging(ectx, L, rows * n * 4, rows * n * 4)      # .inp / .out used as the two halves
-                    try:
-                        halves, k = (stg.inp, stg.out), 0
-                        evs = [C.c_void_p(), C.c_void_p()]
-                        for e_ in evs:
-                            _lib.check(L.pg_event_create(ectx.handle, C.byref(e_)), "pg_event_create")
-                        used = [False, False]
-                        for r0 in range(0, n, rows):
-                            r1 = min(n, r0 + rows)
-                            if used[k]:
-                                _lib.check(L.pg_event_sync(ectx.handle, evs[k]), "pg_event_sync")
-                            _lib.check(L.pg_stage_rows(halves[k], n * 4, Uh.ctypes.data + r0 * n * 4, n * 4, n * 4, r1 - r0, _STAGE_THREADS),
-                                       "pg_stage_rows")
-                            _lib.check(L.pg_memcpy_h2d_async(ectx.handle, dU0.ptr + r0 * n * 4, halves[k], (r1 - r0) * n * 4), "pg_memcpy_h2d_async")
-                            _lib.check(L.pg_event_record(ectx.handle, evs[k]), "pg_event_record")
-                            used[k] = True
-                            k ^= 1
+    comms = None
+    # ONE try/finally owns every resource made from here on (prefetch contexts and threads, the page-lock of X, the communicators,
+    # the eigensolver's context): whatever raises in between — a bad K, os.makedirs, the manifest, a worker — they are released
+    # (every close() below is idempotent, so the earlier explicit ones stay harmless)
+    try:
+        if eigen and eigenpairs is None and not packed and not checkpoint and X.flags.c_contiguous and _PREFETCH_MAX > 0:
+            # the eigensolver leaves PCIe idle for ~0.6 s at n = 10 000 (52 s at 50 000): X starts moving now
+            try:
+                if _lib.is_pinned(X):
+                    pre = _Prefetch(L, X, blocks, n, X.dtype.itemsize, verbose)
+            except _lib.PgError as ex:
+                _log(verbose, f"prefetch not started ({ex})")
+        if eigen:
+            ectx = _lib.Context(0)
+            try:
+                if eigenpairs is not None:
+                    ev, Uh = eigenpairs
+                    Uh = np.asarray(Uh)
+                    if Uh.shape != (n, n):
+                        raise ValueError(f"eigenpairs: U must be ({n},{n}), got {Uh.shape}")
+                    if Uh.dtype != np.float32 or not Uh.flags.c_contiguous:
+                        Uh = np.ascontiguousarray(Uh, np.float32)                       # lmm.py:154
+                    eigenVals = np.maximum(0.0, np.asarray(ev)).astype(np.float32).reshape(-1)   # lmm.py:157-160
+                    if eigenVals.shape[0] != n:
+                        raise ValueError(f"eigenpairs: {n} eigenvalues expected, got {eigenVals.shape}")
+                    dU0 = ectx.alloc(n * n * 4)
+                    if _lib.is_pinned(Uh):     # one DMA straight out of the caller's pinned array
+                        _lib.check(L.pg_memcpy_h2d_async(ectx.handle, dU0.ptr, Uh.ctypes.data, Uh.nbytes), "pg_memcpy_h2d_async")
                         ectx.sync()
-                        for e_ in evs:
-                            L.pg_event_destroy(ectx.handle, e_)
-                    finally:
-                        stg.close()
-                _log(verbose, f"Eigenvectors uploaded ({n * n * 4 / 1e9:.2f} GB) - {time.time() - t0:.3f} s")
-            else:
-                if K.shape != (n, n):
-                    raise ValueError(f"K must be ({n},{n}) when eigen=True, got {K.shape}")
-                if k64:
-                    dK64 = ectx.to_device(np.ascontiguousarray(K))
-                    dK = ectx.alloc(n * n * 4)
-                    _lib.check(L.pg_cast_f64_f32_dev(ectx.handle, n, n, dK64.ptr, n, dK.ptr, n), "pg_cast_f64_f32_dev")   # lmm.py:127-128
-                    ectx.sync()
-                    dK64.free()
+                    else:                      # pageable: row panels through a pinned double buffer, copy threads ahead of the DMA
+                        rows = max(1, min(n, (256 << 20) // (n * 4)))
+                        stg = _Staging(ectx, L, rows * n * 4, rows * n * 4)      # .inp / .out used as the two halves
+                        try:
+                            halves, k = (stg.inp, stg.out), 0
+                            evs = [C.c_void_p(), C.c_void_p()]
+                            for e_ in evs:
+                                _lib.check(L.pg_event_create(ectx.handle, C.byref(e_)), "pg_event_create")
+                            used = [False, False]
+                            for r0 in range(0, n, rows):
+                                r1 = min(n, r0 + rows)
+                                if used[k]:
+                                    _lib.check(L.pg_event_sync(ectx.handle, evs[k]), "pg_event_sync")
+                                _lib.check(L.pg_stage_rows(halves[k], n * 4, Uh.ctypes.data + r0 * n * 4, n * 4, n * 4, r1 - r0, _STAGE_THREADS),
+                                           "pg_stage_rows")
+                                _lib.check(L.pg_memcpy_h2d_async(ectx.handle, dU0.ptr + r0 * n * 4, halves[k], (r1 - r0) * n * 4), "pg_memcpy_h2d_async")
+                                _lib.check(L.pg_event_record(ectx.handle, evs[k]), "pg_event_record")
+                                used[k] = True
+                                k ^= 1
+                            ectx.sync()
+                            for e_ in evs:
+                                L.pg_event_destroy(ectx.handle, e_)
+                        finally:
+                            stg.close()
+                    _log(verbose, f"Eigenvectors uploaded ({n * n * 4 / 1e9:.2f} GB) - {time.time() - t0:.3f} s")
                 else:
-                    dK = ectx.to_device(K)
-                dev, dU0 = ectx.alloc(n * 4), ectx.alloc(n * n * 4)
-                _lib.check(L.pg_syevd_dev(ectx.handle, n, dK.ptr, dev.ptr, dU0.ptr, None, None), "pg_syevd_dev")
-                dK.free()
-                eigenVals = dev.download((n,), np.float32)       # ascending, clamped >= 0, float32 (lmm.py:152-160)
-                _log(verbose, f"Eigendecomposition computed - {time.time() - t0:.3f} s")
-            assert (eigenVals >= 0).all()                    # lmm.py:162
-            t1 = time.time()
-            YW = _rotate_small(ectx, L, n, dU0, np.concatenate([Y.reshape(n, -1)[:, :1], W], axis=1))
-            Yr, Wr = YW[:, :1], np.ascontiguousarray(YW[:, 1:])
-            _log(verbose, f"Left multiplied Y, W by U.T - {time.time() - t1:.3f} s")
-        except BaseException:
-            if pre is not None:
-                pre.close()
-            if xpin is not None:
-                xpin.close()
-            ectx.close()
-            raise
-    else:
-        eigenVals = np.maximum(0.0, K).astype(np.float32).reshape(-1)   # lmm.py:166-167
-        if eigenVals.shape[0] != n:
-            raise ValueError(f"with eigen=False K must hold the {n} eigenvalues, got {K.shape}")
-        Yr, Wr = Y.reshape(n, -1)[:, :1], np.ascontiguousarray(W)
+                    if K.shape != (n, n):
+                        raise ValueError(f"K must be ({n},{n}) when eigen=True, got {K.shape}")
+                    if k64:
+                        dK64 = ectx.to_device(np.ascontiguousarray(K))
+                        dK = ectx.alloc(n * n * 4)
+                        _lib.check(L.pg_cast_f64_f32_dev(ectx.handle, n, n, dK64.ptr, n, dK.ptr, n), "pg_cast_f64_f32_dev")   # lmm.py:127-128
+                        ectx.sync()
+                        dK64.free()
+                    else:
+                        dK = ectx.to_device(K)
+                    dev, dU0 = ectx.alloc(n * 4), ectx.alloc(n * n * 4)
+                    _lib.check(L.pg_syevd_dev(ectx.handle, n, dK.ptr, dev.ptr, dU0.ptr, None, None), "pg_syevd_dev")
+                    dK.free()
+                    eigenVals = dev.download((n,), np.float32)       # ascending, clamped >= 0, float32 (lmm.py:152-160)
+                    _log(verbose, f"Eigendecomposition computed - {time.time() - t0:.3f} s")
+                assert (eigenVals >= 0).all()                    # lmm.py:162
+                t1 = time.time()
+                YW = _rotate_small(ectx, L, n, dU0, np.concatenate([Y.reshape(n, -1)[:, :1], W], axis=1))
+                Yr, Wr = YW[:, :1], np.ascontiguousarray(YW[:, 1:])
+                _log(verbose, f"Left multiplied Y, W by U.T - {time.time() - t1:.3f} s")
+            except BaseException:
+                if pre is not None:
+                    pre.close()
+                if xpin is not None:
+                    xpin.close()
+                ectx.close()
+                raise
+        else:
+            eigenVals = np.maximum(0.0, K).astype(np.float32).reshape(-1)   # lmm.py:166-167
+            if eigenVals.shape[0] != n:
+                raise ValueError(f"with eigen=False K must hold the {n} eigenvalues, got {K.shape}")
+            Yr, Wr = Y.reshape(n, -1)[:, :1], np.ascontiguousarray(W)
 
-    if not disable_checks:
-        # lmm.py:253-256 (the reference tests the rotated arrays; a NaN anywhere in a raw column makes that
-        # whole rotated column NaN, so testing the inputs raises in exactly the same cases)
-        if (not packed and X.dtype.kind == 'f' and np.isnan(X).any()) or np.isnan(Yr).any() or np.isnan(Wr).any():
+        if not disable_checks:
+            # lmm.py:253-256 (the reference tests the rotated arrays; a NaN anywhere in a raw column makes that
+            # whole rotated column NaN, so testing the inputs raises in exactly the same cases)
+            if (not packed and X.dtype.kind == 'f' and np.isnan(X).any()) or np.isnan(Yr).any() or np.isnan(Wr).any():
+                if pre is not None:
+                    pre.close()
+                if xpin is not None:
+                    xpin.close()
+                if ectx is not None:
+                    ectx.close()
+                raise ValueError("NaNs present in data")
+
+        _log(verbose, f"Running {p} SNPs with {n} individuals on {ndev} GPU(s)...")
+        out = {"beta": np.empty(p, np.float32), "se_beta": np.empty(p, np.float32), "tau": np.empty(p, np.float32),
+               "lambda": np.empty(p, np.float64), "F_wald": np.empty(p, np.float64), "p_wald": np.empty(p, np.float64)}
+        if lrt:
+            for col in _LRT_COLS:
+                out[col] = np.empty(p, np.float64)
+        errs, threads = [], []
+        if stats is not None:
+            stats.update({"batches": 0, "bytes_in": 0, "batch_s": 0.0, "gpus": ndev})
+        yr1 = np.ascontiguousarray(Yr.reshape(-1), np.float32)
+        if checkpoint:
+            os.makedirs(checkpoint, exist_ok=True)
+            # identity of the run: shapes, options, batch geometry and the SNP-independent inputs themselves (rotated y, W and the
+            # eigenvalues, byte for byte); the genotypes are fingerprinted per part (_block_fingerprint)
+            key = {"n": int(n), "p": int(p), "c": int(c), "grid": bool(grid), "eigen": bool(eigen), "ndev": int(ndev), "lrt": bool(lrt),
+                   "batch_snps": int(_BATCH_SNPS), "batch_bytes": int(_BATCH_BYTES), "batch_min": int(_BATCH_MIN), "batch_count": int(_BATCH_COUNT),
+                   "y_crc": _crc(yr1), "w_crc": _crc(Wr), "d_crc": _crc(eigenVals)}
+            mf = os.path.join(checkpoint, "manifest.json")
+            if os.path.exists(mf):
+                with open(mf) as f:
+                    if json.load(f) != key:
+                        if ectx is not None:
+                            ectx.close()
+                        raise ValueError(f"checkpoint directory {checkpoint} belongs to a different run (manifest mismatch)")
+            else:
+                with open(mf, "w") as f:
+                    json.dump(key, f)
+        t2 = time.time()
+        comms = None
+        try:
+            if pre is not None:
+                pre.join()
+                if stats is not None:
+                    stats["prefetched_bytes"] = int(pre.bytes)
+            if not packed and not _lib.is_pinned(X):
+                # page-lock the caller's X in place for the duration of the scan (hipHostRegister: ~5 ms/GB measured, tools/bench_h2d.py)
+                # so that every batch is one 2-D DMA straight out of it; if the range cannot be registered (e.g. a read-only file
+                # mapping) the workers fall back to copy threads + a pinned staging buffer
+                try:
+                    xpin = _lib.pin(X)
+                except _lib.PgError as ex:
+                    _log(verbose, f"X could not be page-locked in place ({ex}); staging through pinned buffers")
+            if stats is not None:
+                stats["pinned_input"] = bool((not packed) and _lib.is_pinned(X))
+                stats["registered_in_place"] = xpin is not None
+            dUs = [dU0] + [None] * (ndev - 1)
+            if ndev > 1 and eigen:
+                comms = _make_comms(L, ndev)      # RCCL communicator over the GPUs of this process: U goes GPU 0 -> all over xGMI
+                for g in range(1, ndev):          # receive buffers made here: an allocation failure surfaces before any thread waits in the collective
+                    dUs[g] = comms[g].ctx.alloc(n * n * 4)
+            for dev_id, (a, b) in enumerate(blocks):
+                th = threading.Thread(target=_run_block, args=(dev_id, a, b, n, c, eigenVals, Wr, yr1, X,
+                                                               dUs[dev_id], comms[dev_id] if comms else None,
+                                                               grid, eigen, lrt, out, errs, verbose, checkpoint, stats, pre))
+                th.start()
+                threads.append(th)
+            for th in threads:
+                th.join()
+            if stats is not None:
+                stats["blocks_s"] = time.time() - t2          # page-locking + every GPU's block; what follows is teardown (frees)
+        finally:
             if pre is not None:
                 pre.close()
             if xpin is not None:
                 xpin.close()
+            if comms:
+                for cm in comms:
+                    if cm.handle:
+                        L.pg_comm_destroy(cm.handle)
+                        cm.handle = None
+                    cm.ctx.close()
             if ectx is not None:
                 ectx.close()
-            raise ValueError("NaNs present in data")
-
-    _log(verbose, f"Running {p} SNPs with {n} individuals on {ndev} GPU(s)...")
-    out = {"beta": np.empty(p, np.float32), "se_beta": np.empty(p, np.float32), "tau": np.empty(p, np.float32),
-           "lambda": np.empty(p, np.float64), "F_wald": np.empty(p, np.float64), "p_wald": np.empty(p, np.float64)}
-    if lrt:
-        for col in _LRT_COLS:
-            out[col] = np.empty(p, np.float64)
-    errs, threads = [], []
-    if stats is not None:
-        stats.update({"batches": 0, "bytes_in": 0, "batch_s": 0.0, "gpus": ndev})
-    yr1 = np.ascontiguousarray(Yr.reshape(-1), np.float32)
-    if checkpoint:
-        os.makedirs(checkpoint, exist_ok=True)
-        # identity of the run: shapes, options, batch geometry and the SNP-independent inputs themselves (rotated y, W and the
-        # eigenvalues, byte for byte); the genotypes are fingerprinted per part (_block_fingerprint)
-        key = {"n": int(n), "p": int(p), "c": int(c), "grid": bool(grid), "eigen": bool(eigen), "ndev": int(ndev), "lrt": bool(lrt),
-               "batch_snps": int(_BATCH_SNPS), "batch_bytes": int(_BATCH_BYTES), "batch_min": int(_BATCH_MIN), "batch_count": int(_BATCH_COUNT),
-               "y_crc": _crc(yr1), "w_crc": _crc(Wr), "d_crc": _crc(eigenVals)}
-        mf = os.path.join(checkpoint, "manifest.json")
-        if os.path.exists(mf):
-            with open(mf) as f:
-                if json.load(f) != key:
-                    if ectx is not None:
-                        ectx.close()
-                    raise ValueError(f"checkpoint directory {checkpoint} belongs to a different run (manifest mismatch)")
-        else:
-            with open(mf, "w") as f:
-                json.dump(key, f)
-    t2 = time.time()
-    comms = None
-    try:
-        if pre is not None:
-            pre.join()
-            if stats is not None:
-                stats["prefetched_bytes"] = int(pre.bytes)
-        if not packed and not _lib.is_pinned(X):
-            # page-lock the caller's X in place for the duration of the scan (hipHostRegister: ~5 ms/GB measured, tools/bench_h2d.py)
-            # so that every batch is one 2-D DMA straight out of it; if the range cannot be registered (e.g. a read-only file
-            # mapping) the workers fall back to copy threads + a pinned staging buffer
-            try:
-                xpin = _lib.pin(X)
-            except _lib.PgError as ex:
-                _log(verbose, f"X could not be page-locked in place ({ex}); staging through pinned buffers")
-        if stats is not None:
-            stats["pinned_input"] = bool((not packed) and _lib.is_pinned(X))
-            stats["registered_in_place"] = xpin is not None
-        dUs = [dU0] + [None] * (ndev - 1)
-        if ndev > 1 and eigen:
-            comms = _make_comms(L, ndev)      # RCCL communicator over the GPUs of this process: U goes GPU 0 -> all over xGMI
-            for g in range(1, ndev):          # receive buffers made here: an allocation failure surfaces before any thread waits in the collective
-                dUs[g] = comms[g].ctx.alloc(n * n * 4)
-        for dev_id, (a, b) in enumerate(blocks):
-            th = threading.Thread(target=_run_block, args=(dev_id, a, b, n, c, eigenVals, Wr, yr1, X,
-                                                           dUs[dev_id], comms[dev_id] if comms else None,
-                                                           grid, eigen, lrt, out, errs, verbose, checkpoint, stats, pre))
-            th.start()
-            threads.append(th)
-        for th in threads:
-            th.join()
-        if stats is not None:
-            stats["blocks_s"] = time.time() - t2          # page-locking + every GPU's block; what follows is teardown (frees)
     finally:
         if pre is not None:
             pre.close()
@@ -689,7 +717,9 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
             xpin.close()
         if comms:
             for cm in comms:
-                L.pg_comm_destroy(cm.handle)
+                if cm.handle:
+                    L.pg_comm_destroy(cm.handle)
+                    cm.handle = None
                 cm.ctx.close()
         if ectx is not None:
             ectx.close()
