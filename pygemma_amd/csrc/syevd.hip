@@ -1209,7 +1209,7 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
 }
 
 #ifndef PG_SYEVD2_MIN_N
-#define PG_SYEVD2_MIN_N 2560     // below this the one-stage reduction is as fast or faster (n = 2 001: 54 vs 57 ms; n = 10 000: 0.59 vs 0.48 s)
+#define PG_SYEVD2_MIN_N 3584     // below this the one-stage reduction is as fast or faster (profiles/r03_other_sizes.txt: n = 3 000: 84 vs 83 ms; 4 096: 123 vs 117; 6 000: 223 vs 194; 10 000: 585 vs 461)
 #endif
 #ifndef PG_SYEVD2_MAX_N
 #define PG_SYEVD2_MAX_N 24000    // work space of the two-stage path ~ 12 n^2 doubles
