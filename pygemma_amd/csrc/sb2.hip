@@ -935,6 +935,7 @@ struct Bt2Args {
     const double *Vp, *Vtp;       // block of batch element 0
     long long blk_stride;         // elements between consecutive batch elements
     double *Z;
+    int vec;                      // rows of Z are 16-byte aligned (n even)
 };
 __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
 {
@@ -949,20 +950,47 @@ __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
     const double *V = ar.Vp + (long long)z * ar.blk_stride, *Vt = ar.Vtp + (long long)z * ar.blk_stride;
     double *Zg = ar.Z + (size_t)row0 * n + c0;
     constexpr int CK = BT2_CK, NA = 128 / CK, NB2 = SB_G / CK;
-    // ---- slab in: this wave's 32 columns of all 128 rows (8 row tiles x 2 column tiles)
+    // ---- slab in: this wave's 32 columns of all 128 rows (8 row tiles x 2 column tiles).  Full, 16-byte-aligned slabs come in whole
+    // rows (512 contiguous bytes, 16 per lane) through the operand staging space, 32 rows at a time, and are picked up from LDS in
+    // the accumulator layout; lane-wise 8-byte loads in that layout (64 per lane) were the slow part of the kernel (dgemm's epilogue
+    // had the same disease).  Edge slabs (last columns, odd n) keep the element-wise path.
     doublex4 zr[8][2];
     const int rsub = lane >> 4, csub = lane & 15;
+    const bool vec = ar.vec && ncols == BT2_NS;
+    constexpr int SP2 = BT2_NS + 8;                 // pitch of a staged slab row
+    if (vec) {
 #pragma unroll
-    for (int t = 0; t < 8; t++)
+        for (int ch = 0; ch < 4; ch++) {
+            double2 cv[4];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int col = wn * 32 + j * 16 + csub;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int row = t * 16 + rsub + 4 * e;
-                zr[t][j][e] = (row < h && col < ncols) ? Zg[(size_t)row * n + col] : 0.0;
+            for (int ps = 0; ps < 4; ps++) {
+                const int row = 32 * ch + 8 * ps + (tid >> 5);
+                cv[ps] = (row < h) ? *reinterpret_cast<const double2 *>(Zg + (size_t)row * n + 2 * (tid & 31)) : make_double2(0.0, 0.0);
             }
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++) *reinterpret_cast<double2 *>(As + (8 * ps + (tid >> 5)) * SP2 + 2 * (tid & 31)) = cv[ps];
+            __syncthreads();
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) zr[2 * ch + tt][j][e] = As[(16 * tt + rsub + 4 * e) * SP2 + wn * 32 + j * 16 + csub];
+            __syncthreads();
         }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = wn * 32 + j * 16 + csub;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int row = t * 16 + rsub + 4 * e;
+                    zr[t][j][e] = (row < h && col < ncols) ? Zg[(size_t)row * n + col] : 0.0;
+                }
+            }
+    }
     // ---- phase A: W (64 sweeps x 64 columns) = V' Zs, K = 128 rows; operand chunk = CK rows of V (contiguous doubles)
     doublex4 accA[2][2];
 #pragma unroll
@@ -1074,7 +1102,33 @@ __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
                 }
             }
     };
-    if (wm == 0) store_rows(std::integral_constant<int, 0>{});
+    if (vec) {
+        // chunk ch = rows 32 ch ..: the waves of tile row ch / 2 put Zs - acc into the staging space, then everybody stores whole rows
+        auto stage_rows = [&](auto CH) {
+            constexpr int ch = decltype(CH)::value;
+            if (wm == (ch >> 1)) {
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            As[(16 * tt + rsub + 4 * e) * SP2 + wn * 32 + j * 16 + csub] = zr[2 * ch + tt][j][e] - accB[2 * (ch & 1) + tt][j][e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++) {
+                const int row = 32 * ch + 8 * ps + (tid >> 5);
+                if (row < h)
+                    *reinterpret_cast<double2 *>(Zg + (size_t)row * n + 2 * (tid & 31)) = *reinterpret_cast<const double2 *>(As + (8 * ps + (tid >> 5)) * SP2 + 2 * (tid & 31));
+            }
+            __syncthreads();
+        };
+        stage_rows(std::integral_constant<int, 0>{});
+        stage_rows(std::integral_constant<int, 1>{});
+        stage_rows(std::integral_constant<int, 2>{});
+        stage_rows(std::integral_constant<int, 3>{});
+    } else if (wm == 0) store_rows(std::integral_constant<int, 0>{});
     else store_rows(std::integral_constant<int, 1>{});
 }
 
@@ -1122,7 +1176,7 @@ int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w, bool prepared)
         Bt2Args ar;
         ar.n = n; ar.nb = nb; ar.row_first = row_first; ar.h_last = std::min<long long>(HGT, n - row_last);
         ar.Vp = w.Vp + ((size_t)kmin * ng + G0) * blk; ar.Vtp = w.Vtp + ((size_t)kmin * ng + G0) * blk;
-        ar.blk_stride = (long long)(ng + 1) * blk; ar.Z = Z;
+        ar.blk_stride = (long long)(ng + 1) * blk; ar.Z = Z; ar.vec = ((n & 1) == 0 && (uintptr_t)Z % 16 == 0) ? 1 : 0;
         bt2_apply_kernel<<<dim3(nslab, nb), 256, BT2_LDS_BYTES, st>>>(ar);
     }
     PG_HIP(hipGetLastError());
