@@ -230,7 +230,12 @@ int pg_kinship_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *G, int64
 /* ---- H1: eigendecomposition of K (lmm/lmm.py:151-162 / :196-207, scipy.linalg.eigh = LAPACK ssyevr)
  * Reads the LOWER triangle of row-major K (n x n, float32, device).  Computes in fp64; delivers ascending
  * eigenvalues clamped at 0 (lmm/lmm.py:157) as float32, and U (column j = eigenvector j) as float32
- * (and optionally fp64 for the invariant checks: U64/evals64 may be NULL). */
+ * (and optionally fp64 for the invariant checks: U64/evals64 may be NULL).
+ * Two reductions to tridiagonal form behind this one entry point: from n = 3584 on, dense -> band (fp64 MFMA GEMMs) -> tridiagonal
+ * (persistent bulge-chasing kernel) with two blocked back-transformations (csrc/sb2.hip); below that, and for a K whose panels the
+ * band reduction cannot factor (rank-deficient K: decided on the device), the one-stage Householder reduction (csrc/syevd.hip).
+ * Environment, for tests and A/B timing only: PG_SYEVD_STAGES=1|2 forces a path, PG_SYEVD_TIMING=1 prints phase times.
+ * Work space ~ 12 n^2 doubles on the two-stage path (n <= 24 000), ~ 8 n^2 on the one-stage path. */
 int pg_syevd_dev(pg_ctx *ctx, int64_t n, const float *K, float *evals, float *U, double *evals64, double *U64);
 
 /* ---- Inspection surface: the model-level functions the reference's tests call directly

@@ -247,8 +247,16 @@ __global__ __launch_bounds__(256) void recon_kernel(const double *G2, const doub
     mm64([&](int a, int k) { return M0[a * P65 + k]; }, [&](int k, int b) { return M2[k * P65 + b]; },
          [&](int a, int b, double v) { Rprod[a * B + b] = v; }, tid);              // R2 R1 (scaled by D on the way out)
     __syncthreads();                                                              // R1 is done with: M2 takes the top block of Q
-    mm64([&](int a, int k) { return Q1top[a * B + k]; }, [&](int k, int b) { return M1[k * P65 + b]; },
-         [&](int a, int b, double v) { M2[a * P65 + b] = v; }, tid);               // M2 = top block of Q = Q1 R2^-1
+    load64(M2, Q1top, B, tid);                                                    // Q1's top block through LDS (it was read from global inside the product)
+    __syncthreads();
+    {
+        double qv[16];
+        mm64([&](int a, int k) { return M2[a * P65 + k]; }, [&](int k, int b) { return M1[k * P65 + b]; },
+             [&](int, int b, double v) { qv[b & 15] = v; }, tid);
+        __syncthreads();                                                          // every read of Q1's top block is done
+#pragma unroll
+        for (int q = 0; q < 16; q++) M2[i * P65 + j0 + q] = qv[q];                  // M2 = top block of Q = Q1 R2^-1
+    }
     __syncthreads();
     // LU of E - Q D without pivoting on the top block: ONE wavefront, the matrix in registers (lane j = column j), right-looking with
     // compile-time lane numbers (v_readlane) — no LDS traffic, no barriers inside the 64 steps.  After step k row k holds the
