@@ -402,7 +402,7 @@ size_t sb2_bytes(int n)
     const size_t nn = (size_t)n * n;
     const size_t ng = ((size_t)n + SB_G - 1) / SB_G + 1, kmax = ((size_t)n + B - 1) / B + 1;
     return 8 * (2 * nn + (size_t)n * 4 * B + (size_t)n * SB_LD + (size_t)n * (kmax + 1) + 2 * ng * kmax * 128 * SB_G + (kmax + 1) * SB_G * n +
-                (ng + 1) * B * B + 2 * (size_t)BT1_BLOCK * BT1_BLOCK + 2 * (size_t)BT1_BLOCK * n + 64 * B * B) + 4 * ((size_t)n + 64);
+                (ng + 1) * B * B + 2 * (size_t)BT1_BLOCK * BT1_BLOCK + 2 * (size_t)BT1_BLOCK * n + 64 * B * B + (kmax + 1) * SB_MAIL_LD) + 4 * ((size_t)n + 64);
 }
 
 static int alloc_d2(double **p, size_t count)
@@ -427,7 +427,7 @@ int sb2_alloc(int n, Sb2Work &w)
         {&w.Vst, nn}, {&w.Tst, (size_t)(w.npan + 1) * B * B}, {&w.VW, ((size_t)n + 384) * 2 * B}, {&w.Qb, ((size_t)n + 384) * B}, {&w.sm, (size_t)16 * B * B},
         {&w.S, ((size_t)n + 2) * SB_LD}, {&w.VV, nn}, {&w.TAU, (size_t)n * w.nk}, {&w.Vp, (size_t)w.ng * w.kmax * 128 * SB_G},
         {&w.Vtp, (size_t)w.ng * w.kmax * 128 * SB_G}, {&w.Wws, ((size_t)w.kmax + 1) * SB_G * n}, {&w.G, (size_t)BT1_BLOCK * BT1_BLOCK},
-        {&w.T, (size_t)BT1_BLOCK * BT1_BLOCK}, {&w.W, (size_t)BT1_BLOCK * n}, {&w.W2, (size_t)BT1_BLOCK * n}};
+        {&w.T, (size_t)BT1_BLOCK * BT1_BLOCK}, {&w.W, (size_t)BT1_BLOCK * n}, {&w.W2, (size_t)BT1_BLOCK * n}, {&w.mail, ((size_t)w.kmax + 1) * SB_MAIL_LD}};
     for (auto &r : req) { if (!rc) rc = alloc_d2(r.p, r.cnt); }
     if (!rc && hipMalloc(&w.prog, ((size_t)n + 16) * sizeof(int)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
     if (!rc && hipMalloc(&w.fail, 4 * sizeof(int)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
@@ -437,7 +437,7 @@ int sb2_alloc(int n, Sb2Work &w)
 
 void sb2_free(Sb2Work &w)
 {
-    for (double *p : {w.Vst, w.Tst, w.VW, w.Qb, w.sm, w.S, w.VV, w.TAU, w.Vp, w.Vtp, w.Wws, w.G, w.T, w.W, w.W2}) if (p) (void)hipFree(p);
+    for (double *p : {w.Vst, w.Tst, w.VW, w.Qb, w.sm, w.S, w.VV, w.TAU, w.Vp, w.Vtp, w.Wws, w.G, w.T, w.W, w.W2, w.mail}) if (p) (void)hipFree(p);
     if (w.prog) (void)hipFree(w.prog);
     if (w.fail) (void)hipFree(w.fail);
     w = Sb2Work{};
@@ -637,7 +637,7 @@ constexpr int WP = SB_LD + 1;       // LDS pitch of one band row (129 doubles: r
 #define PG_BC_WAVES 16              // wavefronts per workgroup: several per SIMD hide each other's LDS latency (busy time per step at n = 10 000: 4 waves 8.4 us, 8: 5.2, 16: 4.9)
 #endif
 constexpr int NW = PG_BC_WAVES, RW = B / NW;     // RW: rows (or columns) of a 64 x 64 block per wavefront
-constexpr int BC_LDS_BYTES = (B * WP + 4 * B + 2 * NW * B + 2) * 8;
+constexpr int BC_LDS_BYTES = (B * WP + 4 * B + 2 * NW * B + 4) * 8;    // band rows | v, v', w, q | partial sums | tau, beta, tau', abort
 
 // sum over the 64 lanes, returned to every lane: DPP inside each row of 16 lanes (no LDS round trips), the four row sums
 // combined through scalar registers
@@ -833,6 +833,202 @@ __global__ __launch_bounds__(64 * NW) void bc_kernel(int n, double *S, double *V
 #endif
 }
 
+// ---- stage 2, band rows stationary in LDS ------------------------------------------------------------------------------------------
+// The kernel above carries every step's 64 rows through memory (load, store, flag: about half of a step's 11 us).  When the
+// matrix has no more row blocks than the chip has CUs, the rows can stay where they are worked on: workgroup K keeps the 64 rows
+// s + 1 + 64 K .. of sweep s in a ring in LDS (row i in ring slot i & 63) and does step (s, K) of every sweep.  Between two sweeps
+// its window slides down by one row: the top row leaves for workgroup K - 1 (workgroup 0: it is final, to memory), the new bottom
+// row arrives from workgroup K + 1, and the reflector of step (s, K) goes down to workgroup K + 1, which applies it from the
+// right.  These three messages of <= 1 KB (a mailbox per workgroup in memory: write-through 16-byte stores, drain, sequence flag)
+// are all the memory traffic of a step.  One mailbox slot per direction is enough: the dependences of the sweeps themselves order
+// each send after the receiver has read the previous one.
+//   mailbox of workgroup K (MB_LD doubles): [0, 128) the row going up | [128, 192) the reflector going down, [192] its tau |
+//   ints at double 208: sequence of the row (sweep + 1) | at double 224: sequence of the reflector
+constexpr int MB_LD = SB_MAIL_LD, MB_V = 128, MB_SEQ_UP = 208 * 2, MB_SEQ_DOWN = 224 * 2;
+
+// lane 0 of the calling wavefront waits for *flag >= want; false (and the abort flag raised) when the wait expired or another
+// workgroup gave up
+__device__ __forceinline__ bool bc_wait(const int *flag, int want, int *ctl, int *fail, int s, int K)
+{
+    bool ok = true;
+    if ((threadIdx.x & 63) == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
+            if (++spins > (1 << 20)) {           // never expected: every workgroup of the grid is resident; do not hang the GPU
+                __hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (atomicOr(&fail[1], 1) == 0) { fail[2] = s; fail[3] = K; }
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    asm volatile("" ::: "memory");
+    return ok;
+}
+
+__global__ __launch_bounds__(64 * NW) void bc_stationary_kernel(int n, double *S, double *VV, double *TAU, int nk, double *mail, int nwg, int *ctl, int *fail)
+{
+    extern __shared__ double bc_lds[];
+    double *Wn = bc_lds;
+    double *vcur = Wn + B * WP, *vprev = vcur + B, *wv = vprev + B, *qv = wv + B;
+    double (*part)[B] = reinterpret_cast<double (*)[B]>(qv + B);
+    double (*part2)[B] = part + NW;
+    double *sc = reinterpret_cast<double *>(part2 + NW);     // [0] tau, [1] beta of this step, [2] tau of the reflector from above
+    int *abort_sh = reinterpret_cast<int *>(sc + 3);
+    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
+    const int K = blockIdx.x;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(S, 0, (int)((size_t)(n + 2) * SB_LD * 8), 0x00020000);
+    const auto rmail = __builtin_amdgcn_make_buffer_rsrc(mail, 0, (int)((size_t)nwg * MB_LD * 8), 0x00020000);
+    int *mflag = reinterpret_cast<int *>(mail);
+    // the window of sweep 0
+#pragma unroll
+    for (int rr = 0; rr < RW; rr++) {
+        const int i = 1 + K * B + RW * wq + rr;
+        double v0 = 0.0, v1 = 0.0;
+        if (i < n) unpack2(__builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)((i * SB_LD + 2 * lane) * 8), 0, 0), v0, v1);
+        Wn[(i & (B - 1)) * WP + 2 * lane] = v0;
+        Wn[(i & (B - 1)) * WP + 2 * lane + 1] = v1;
+    }
+    if (tid < B) vprev[tid] = 0.0;
+    if (tid == 0) { sc[2] = 0.0; *abort_sh = 0; }
+    __syncthreads();
+    int s = 0;
+    for (; s <= n - 3; s++) {
+        const int r0 = s + 1 + K * B;
+        if (r0 >= n) break;
+        const int L = (n - r0 < B) ? n - r0 : B;
+        const int eb = (r0 - B) & (SB_LD - 1), db = r0 & (SB_LD - 1), rb = r0 & (B - 1);
+        const int ecol = (eb + lane) & (SB_LD - 1), dcol = (db + lane) & (SB_LD - 1);
+#define ROW(rl_) ((((rl_) + rb) & (B - 1)) * WP)
+#define EIX(rl_, c_) (ROW(rl_) + ((eb + (c_)) & (SB_LD - 1)))
+#define DIX(rl_, c_) (ROW(rl_) + ((db + (c_)) & (SB_LD - 1)))
+        // ---- receive: the new bottom row (row r0 + 63 was the top row of step (s - 1, K + 1)) and the reflector of step (s, K - 1)
+        if (wq == 1 && s >= 1) {
+            double v0 = 0.0, v1 = 0.0;
+            if (r0 + B - 1 < n) {
+                if (!bc_wait(&mflag[(size_t)(K + 1) * MB_LD * 2 + MB_SEQ_UP], s, ctl, fail, s, K)) *abort_sh = 1;
+                unpack2(__builtin_amdgcn_raw_buffer_load_b128(rmail, (unsigned)(((K + 1) * MB_LD + 2 * lane) * 8), 0, BC_SC1), v0, v1);
+            }
+            Wn[ROW(B - 1) + 2 * lane] = v0;
+            Wn[ROW(B - 1) + 2 * lane + 1] = v1;
+        }
+        if (wq == 0 && K >= 1) {
+            if (!bc_wait(&mflag[(size_t)(K - 1) * MB_LD * 2 + MB_SEQ_DOWN], s + 1, ctl, fail, s, K)) *abort_sh = 1;
+            if (lane <= B / 2) {
+                double v0, v1;
+                unpack2(__builtin_amdgcn_raw_buffer_load_b128(rmail, (unsigned)(((K - 1) * MB_LD + MB_V + 2 * lane) * 8), 0, BC_SC1), v0, v1);
+                if (lane < B / 2) { vprev[2 * lane] = v0; vprev[2 * lane + 1] = v1; }
+                else sc[2] = v0;
+            }
+        }
+        __syncthreads();
+        if (*abort_sh != 0) return;
+        const double taup = sc[2];
+        double x0 = 0.0;
+        // ---- (1) right-apply the reflector from above to E (lane = row, wq = RW columns)
+        if (K >= 1) {
+            double s_ = 0.0;
+#pragma unroll
+            for (int c = RW * wq; c < RW * wq + RW; c++) s_ = fma(Wn[EIX(lane, c)], vprev[c], s_);
+            part[wq][lane] = s_;
+            __syncthreads();
+            double u = 0.0;
+#pragma unroll
+            for (int w_ = 0; w_ < NW; w_++) u += part[w_][lane];
+            const double tu = taup * u;
+#pragma unroll
+            for (int c = RW * wq; c < RW * wq + RW; c++) Wn[EIX(lane, c)] = fma(-tu, vprev[c], Wn[EIX(lane, c)]);
+            if (wq == 0) x0 = Wn[EIX(lane, 0)];
+        } else if (wq == 0) x0 = Wn[EIX(lane, B - 1)];
+        // ---- (2) reflector (wave 0)
+        if (wq == 0) {
+            const double alpha = readlane_d(x0, 0);
+            const double xn2 = wave_sum_dpp((lane >= 1) ? x0 * x0 : 0.0);
+            double beta = alpha, tau = 0.0, scal = 0.0;
+            if (xn2 != 0.0) { beta = -copysign(sqrt(alpha * alpha + xn2), alpha); tau = (beta - alpha) / beta; scal = 1.0 / (alpha - beta); }
+            const double v = (lane == 0) ? 1.0 : x0 * scal;
+            vcur[lane] = v;
+            if (lane == 0) { sc[0] = tau; sc[1] = beta; TAU[(size_t)s * nk + K] = tau; }
+            if (lane < L) VV[(size_t)s * n + r0 + lane] = v;
+            Wn[EIX(lane, (K >= 1) ? 0 : B - 1)] = (lane == 0) ? beta : 0.0;
+        }
+        __syncthreads();
+        const double tau = sc[0];
+        // the reflector leaves for workgroup K + 1 (last wave: its stores drain behind the products below)
+        const bool send_down = (wq == NW - 1) && (r0 + B < n);
+        if (send_down && lane <= B / 2) {
+            const double a_ = (lane < B / 2) ? vcur[2 * lane] : tau, b_ = (lane < B / 2) ? vcur[2 * lane + 1] : 0.0;
+            __builtin_amdgcn_raw_buffer_store_b128(pack2(a_, b_), rmail, (unsigned)((K * MB_LD + MB_V + 2 * lane) * 8), 0, BC_SC1);
+        }
+        // ---- (3a), (4a) w = E'v, p = D v   (lane = column, wq = RW rows)
+        {
+            double sw = 0.0, sp = 0.0;
+#pragma unroll
+            for (int r = RW * wq; r < RW * wq + RW; r++) {
+                const double vr = vcur[r];
+                sp = fma(Wn[(r >= lane) ? ROW(r) + dcol : DIX(lane, r)], vr, sp);
+                if (K >= 1) sw = fma(Wn[ROW(r) + ecol], vr, sw);
+            }
+            part[wq][lane] = sw;
+            part2[wq][lane] = sp;
+        }
+        if (send_down) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&mflag[(size_t)K * MB_LD * 2 + MB_SEQ_DOWN], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (wq == 0) {
+            double w_ = 0.0;
+#pragma unroll
+            for (int q = 0; q < NW; q++) w_ += part[q][lane];
+            wv[lane] = w_;
+        }
+        if (wq == 1) {
+            double p = 0.0;
+#pragma unroll
+            for (int q = 0; q < NW; q++) p += part2[q][lane];
+            p *= tau;
+            const double pv = wave_sum_dpp(p * vcur[lane]);
+            qv[lane] = p - 0.5 * tau * pv * vcur[lane];
+        }
+        __syncthreads();
+        // ---- (3b), (4b) rank updates in place (lane = column, wq = RW rows)
+        {
+            const double wc = wv[lane], qc = qv[lane], vc = vcur[lane];
+#pragma unroll
+            for (int r = RW * wq; r < RW * wq + RW; r++) {
+                const double vr = vcur[r], qr = qv[r];
+                if (K >= 1 && lane >= 1) Wn[ROW(r) + ecol] = fma(-tau * vr, wc, Wn[ROW(r) + ecol]);
+                if (lane <= r) Wn[ROW(r) + dcol] -= vr * qc + qr * vc;
+            }
+        }
+        // the top row is finished (all of it was updated by this wavefront): it leaves for workgroup K - 1, or for memory
+        if (wq == 0) {
+            const u32x4 rowv = pack2(Wn[ROW(0) + 2 * lane], Wn[ROW(0) + 2 * lane + 1]);
+            if (K == 0) __builtin_amdgcn_raw_buffer_store_b128(rowv, rsrc, (unsigned)((r0 * SB_LD + 2 * lane) * 8), 0, 0);
+            else {
+                __builtin_amdgcn_raw_buffer_store_b128(rowv, rmail, (unsigned)((K * MB_LD + 2 * lane) * 8), 0, BC_SC1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&mflag[(size_t)K * MB_LD * 2 + MB_SEQ_UP], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+#undef ROW
+#undef EIX
+#undef DIX
+    }
+    // the rows still in the window go back to memory
+#pragma unroll
+    for (int rr = 0; rr < RW; rr++) {
+        const int i = s + 1 + K * B + RW * wq + rr;
+        if (i < n)
+            __builtin_amdgcn_raw_buffer_store_b128(pack2(Wn[(i & (B - 1)) * WP + 2 * lane], Wn[(i & (B - 1)) * WP + 2 * lane + 1]), rsrc,
+                                                   (unsigned)((i * SB_LD + 2 * lane) * 8), 0, 0);
+    }
+}
+
 int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2Work &w)
 {
     hipStream_t st = ctx->stream;
@@ -841,17 +1037,28 @@ int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2W
     PG_HIP(hipMemsetAsync(w.VV, 0, (size_t)n * n * 8, st));
     PG_HIP(hipMemsetAsync(w.TAU, 0, (size_t)n * w.nk * 8, st));
     if (n >= 3) {
-        // a sweep trails the one ahead by two blocks: n / 128 sweeps are in flight at most; workgroups beyond that would only poll
-        int nwg = n / (2 * B) + 4;
-        nwg = std::max(1, std::min(nwg, std::min(ctx->num_cu, 256)));
-        if (const char *e_ = getenv("PG_BC_NWG")) nwg = std::max(1, std::min(atoi(e_), 256));     // A/B and debugging
         constexpr int BC_LDS = BC_LDS_BYTES;
         static bool attr_done = false;
         if (!attr_done) {
             PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS));
+            PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_stationary_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS));
             attr_done = true;
         }
-        bc_kernel<<<nwg, 64 * NW, BC_LDS, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.prog, w.prog + n, w.fail, g_bc_debug);
+        // one workgroup per block of 64 rows, all of them resident at once (they wait for each other): only while the chip has a CU
+        // for each; larger matrices take the kernel that carries the rows through memory
+        const int nblk = (n - 1 + B - 1) / B;
+        bool stationary = nblk <= std::min(ctx->num_cu, w.kmax);
+        if (const char *e_ = getenv("PG_BC_STATIONARY")) stationary = stationary && atoi(e_) != 0;
+        if (stationary) {
+            PG_HIP(hipMemsetAsync(w.mail, 0, (size_t)nblk * MB_LD * 8, st));
+            bc_stationary_kernel<<<nblk, 64 * NW, BC_LDS, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.mail, nblk, w.prog + n, w.fail);
+        } else {
+            // a sweep trails the one ahead by two blocks: n / 128 sweeps are in flight at most; workgroups beyond that would only poll
+            int nwg = n / (2 * B) + 4;
+            nwg = std::max(1, std::min(nwg, std::min(ctx->num_cu, 256)));
+            if (const char *e_ = getenv("PG_BC_NWG")) nwg = std::max(1, std::min(atoi(e_), 256));     // A/B and debugging
+            bc_kernel<<<nwg, 64 * NW, BC_LDS, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.prog, w.prog + n, w.fail, g_bc_debug);
+        }
     }
     band_de_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, w.S, d, e);
     PG_HIP(hipGetLastError());

@@ -7,6 +7,7 @@ namespace pg {
 constexpr int SB_B = 64;     // half-width of the band the first stage reduces to = reflector length of the second stage
 constexpr int SB_G = 64;     // sweeps per reflector block of the second stage's back-transformation
 constexpr int SB_LD = 2 * SB_B;   // row pitch of the compact band storage (band + room for the bulge)
+constexpr int SB_MAIL_LD = 256;   // doubles per workgroup mailbox of the stationary bulge-chasing kernel
 
 // work buffers of one solve; every pointer device memory, owned by the caller of sb2_alloc / sb2_free
 struct Sb2Work {
@@ -22,6 +23,7 @@ struct Sb2Work {
     double *Vp = nullptr, *Vtp = nullptr;   // kmax x ng blocks of 128 x SB_G: parallelogram blocks V and V T
     double *Wws = nullptr;    // (kmax + 1) x SB_G x n
     double *G = nullptr, *T = nullptr, *W = nullptr, *W2 = nullptr;   // stage-1 back-transformation (blocks of 256 reflectors)
+    double *mail = nullptr;   // (kmax + 1) x SB_MAIL_LD: mailboxes of the stationary bulge-chasing kernel
     int *prog = nullptr;      // n + 16 ints: per-sweep progress | work-queue head | abort flag
     int *fail = nullptr;      // 4 ints: [0] panel factorisation lost orthogonality / not positive definite, [1] bulge-chase wait expired
 };

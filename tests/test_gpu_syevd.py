@@ -190,9 +190,11 @@ def test_syevd_structured_matrices(name, n, stages, ctx, monkeypatch):
     assert (ev32 >= 0).all() and np.isfinite(U32).all()
 
 
+@pytest.mark.parametrize("stationary", [1, 0])
 @pytest.mark.parametrize("n", [192, 300, 777, 1300])
-def test_two_stage_pieces(n, ctx):
-    """The two stages of the tridiagonalisation one at a time (csrc/sb2.hip), against fp64 LAPACK:
+def test_two_stage_pieces(n, stationary, ctx, monkeypatch):
+    """The two stages of the tridiagonalisation one at a time (csrc/sb2.hip), against fp64 LAPACK, with both bulge-chasing kernels
+    (band rows stationary in LDS — the default up to one row block per CU — and rows carried through memory):
     stage 1: the band matrix keeps K's spectrum, Q1 (the back-transformation applied to I) is orthogonal and Q1 B Q1' = K, no panel
              needed the fallback on a full-rank K;
     stage 2: the tridiagonal keeps the band's spectrum, Q2 orthogonal, Q2 T Q2' = B, no wait of the bulge-chasing kernel expired."""
@@ -215,6 +217,7 @@ def test_two_stage_pieces(n, ctx):
     assert np.abs(Q1 @ Bm @ Q1.T - K64).max() <= 1e-12 * nrm
     dB, dd, de = ctx.to_device(Bm), ctx.alloc(n * 8), ctx.alloc(n * 8)
     dZ.upload(np.eye(n))
+    monkeypatch.setenv("PG_BC_STATIONARY", str(stationary))
     _lib.check(L.pgx_sb2_stage2_dev(ctx.handle, n, dB.ptr, dd.ptr, de.ptr, dZ.ptr, flags), "stage 2")
     assert list(flags)[:2] == [0, 0]
     d, e, Q2 = dd.download((n,), np.float64), de.download((n,), np.float64)[: n - 1], dZ.download((n, n), np.float64)
