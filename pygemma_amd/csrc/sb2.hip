@@ -839,34 +839,29 @@ __global__ __launch_bounds__(64 * NW) void bc_kernel(int n, double *S, double *V
 // s + 1 + 64 K .. of sweep s in a ring in LDS (row i in ring slot i & 63) and does step (s, K) of every sweep.  Between two sweeps
 // its window slides down by one row: the top row leaves for workgroup K - 1 (workgroup 0: it is final, to memory), the new bottom
 // row arrives from workgroup K + 1, and the reflector of step (s, K) goes down to workgroup K + 1, which applies it from the
-// right.  These three messages of <= 1 KB (a mailbox per workgroup in memory: write-through 16-byte stores, drain, sequence flag)
-// are all the memory traffic of a step.  One mailbox slot per direction is enough: the dependences of the sweeps themselves order
+// right.  These three messages (a mailbox per workgroup in memory, write-through 16-byte stores) are all the memory traffic of a
+// step.  One mailbox slot per direction is enough: the dependences of the sweeps themselves order
 // each send after the receiver has read the previous one.
-//   mailbox of workgroup K (MB_LD doubles): [0, 128) the row going up | [128, 192) the reflector going down, [192] its tau |
-//   ints at double 208: sequence of the row (sweep + 1) | at double 224: sequence of the reflector
-constexpr int MB_LD = SB_MAIL_LD, MB_V = 128, MB_SEQ_UP = 208 * 2, MB_SEQ_DOWN = 224 * 2;
-
-// lane 0 of the calling wavefront waits for *flag >= want; false (and the abort flag raised) when the wait expired or another
-// workgroup gave up
-__device__ __forceinline__ bool bc_wait(const int *flag, int want, int *ctl, int *fail, int s, int K)
+// Message format: every double travels as one 16-byte chunk {low word, tag, high word, tag} with tag = sweep + 1, so each aligned
+// 8-byte half validates itself (8-byte accesses are single-copy atomic) and the receiver polls the payload directly: no drain,
+// no separate flag, no second round trip (the first version — payload, s_waitcnt, sequence flag, then the receiver's two dependent
+// loads — spent 2.1 us per hop; the sweep period is two hops plus the work between them).
+//   mailbox of workgroup K (MB_LD doubles = 4 KB): chunks [0, 128) the row going up | chunks [128, 192) the reflector going down,
+//   chunk 192 its tau
+constexpr int MB_LD = SB_MAIL_LD, MB_V = 128, MB_TAU = 192;
+__device__ __forceinline__ u32x4 mb_pack(double x, unsigned tag) { return u32x4{(unsigned)__double2loint(x), tag, (unsigned)__double2hiint(x), tag}; }
+__device__ __forceinline__ double mb_value(u32x4 c) { return __hiloint2double((int)c.z, (int)c.x); }
+// after an expired wait: raise the abort flag for every workgroup and leave a note
+__device__ __forceinline__ void bc_give_up(int *ctl, int *fail, int s, int K)
 {
-    bool ok = true;
     if ((threadIdx.x & 63) == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            if (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
-            if (++spins > (1 << 20)) {           // never expected: every workgroup of the grid is resident; do not hang the GPU
-                __hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (atomicOr(&fail[1], 1) == 0) { fail[2] = s; fail[3] = K; }
-                ok = false;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
+        __hip_atomic_store(&ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (atomicOr(&fail[1], 1) == 0) { fail[2] = s; fail[3] = K; }
     }
-    asm volatile("" ::: "memory");
-    return ok;
 }
+#define BC_POLL_GUARD(spins_, ctl_, bad_)                                                                                         \
+    if ((++(spins_) & 63) == 0 &&                                                                                                 \
+        ((spins_) > (1 << 20) || __hip_atomic_load(&(ctl_)[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { (bad_) = true; break; }
 
 __global__ __launch_bounds__(64 * NW) void bc_stationary_kernel(int n, double *S, double *VV, double *TAU, int nk, double *mail, int nwg, int *ctl, int *fail)
 {
@@ -881,7 +876,6 @@ __global__ __launch_bounds__(64 * NW) void bc_stationary_kernel(int n, double *S
     const int K = blockIdx.x;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(S, 0, (int)((size_t)(n + 2) * SB_LD * 8), 0x00020000);
     const auto rmail = __builtin_amdgcn_make_buffer_rsrc(mail, 0, (int)((size_t)nwg * MB_LD * 8), 0x00020000);
-    int *mflag = reinterpret_cast<int *>(mail);
     // the window of sweep 0
 #pragma unroll
     for (int rr = 0; rr < RW; rr++) {
@@ -908,20 +902,40 @@ __global__ __launch_bounds__(64 * NW) void bc_stationary_kernel(int n, double *S
         if (wq == 1 && s >= 1) {
             double v0 = 0.0, v1 = 0.0;
             if (r0 + B - 1 < n) {
-                if (!bc_wait(&mflag[(size_t)(K + 1) * MB_LD * 2 + MB_SEQ_UP], s, ctl, fail, s, K)) *abort_sh = 1;
-                unpack2(__builtin_amdgcn_raw_buffer_load_b128(rmail, (unsigned)(((K + 1) * MB_LD + 2 * lane) * 8), 0, BC_SC1), v0, v1);
+                const unsigned want = (unsigned)s, off = (unsigned)(((K + 1) * MB_LD * 8) + 32 * lane);
+                u32x4 c0, c1;
+                int spins = 0;
+                bool bad = false;
+                for (;;) {
+                    c0 = __builtin_amdgcn_raw_buffer_load_b128(rmail, off, 0, BC_SC1);
+                    c1 = __builtin_amdgcn_raw_buffer_load_b128(rmail, off + 16, 0, BC_SC1);
+                    asm volatile("" ::: "memory");
+                    if (__all(c0.y == want && c0.w == want && c1.y == want && c1.w == want)) break;
+                    BC_POLL_GUARD(spins, ctl, bad)
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (bad) { bc_give_up(ctl, fail, s, K); *abort_sh = 1; }
+                v0 = mb_value(c0); v1 = mb_value(c1);
             }
             Wn[ROW(B - 1) + 2 * lane] = v0;
             Wn[ROW(B - 1) + 2 * lane + 1] = v1;
         }
         if (wq == 0 && K >= 1) {
-            if (!bc_wait(&mflag[(size_t)(K - 1) * MB_LD * 2 + MB_SEQ_DOWN], s + 1, ctl, fail, s, K)) *abort_sh = 1;
-            if (lane <= B / 2) {
-                double v0, v1;
-                unpack2(__builtin_amdgcn_raw_buffer_load_b128(rmail, (unsigned)(((K - 1) * MB_LD + MB_V + 2 * lane) * 8), 0, BC_SC1), v0, v1);
-                if (lane < B / 2) { vprev[2 * lane] = v0; vprev[2 * lane + 1] = v1; }
-                else sc[2] = v0;
+            const unsigned want = (unsigned)(s + 1), base = (unsigned)((K - 1) * MB_LD * 8);
+            u32x4 c0, c1;
+            int spins = 0;
+            bool bad = false;
+            for (;;) {
+                c0 = __builtin_amdgcn_raw_buffer_load_b128(rmail, base + 16 * (MB_V + lane), 0, BC_SC1);
+                c1 = __builtin_amdgcn_raw_buffer_load_b128(rmail, base + 16 * MB_TAU, 0, BC_SC1);
+                asm volatile("" ::: "memory");
+                if (__all(c0.y == want && c0.w == want && c1.y == want && c1.w == want)) break;
+                BC_POLL_GUARD(spins, ctl, bad)
+                __builtin_amdgcn_s_sleep(1);
             }
+            if (bad) { bc_give_up(ctl, fail, s, K); *abort_sh = 1; }
+            vprev[lane] = mb_value(c0);
+            if (lane == 0) sc[2] = mb_value(c1);
         }
         __syncthreads();
         if (*abort_sh != 0) return;
@@ -956,11 +970,11 @@ __global__ __launch_bounds__(64 * NW) void bc_stationary_kernel(int n, double *S
         }
         __syncthreads();
         const double tau = sc[0];
-        // the reflector leaves for workgroup K + 1 (last wave: its stores drain behind the products below)
-        const bool send_down = (wq == NW - 1) && (r0 + B < n);
-        if (send_down && lane <= B / 2) {
-            const double a_ = (lane < B / 2) ? vcur[2 * lane] : tau, b_ = (lane < B / 2) ? vcur[2 * lane + 1] : 0.0;
-            __builtin_amdgcn_raw_buffer_store_b128(pack2(a_, b_), rmail, (unsigned)((K * MB_LD + MB_V + 2 * lane) * 8), 0, BC_SC1);
+        // the reflector leaves for workgroup K + 1 (last wavefront; nothing waits for these stores)
+        if (wq == NW - 1 && r0 + B < n) {
+            const unsigned tag = (unsigned)(s + 1);
+            __builtin_amdgcn_raw_buffer_store_b128(mb_pack(vcur[lane], tag), rmail, (unsigned)(K * MB_LD * 8 + 16 * (MB_V + lane)), 0, BC_SC1);
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(mb_pack(tau, tag), rmail, (unsigned)(K * MB_LD * 8 + 16 * MB_TAU), 0, BC_SC1);
         }
         // ---- (3a), (4a) w = E'v, p = D v   (lane = column, wq = RW rows)
         {
@@ -973,10 +987,6 @@ __global__ __launch_bounds__(64 * NW) void bc_stationary_kernel(int n, double *S
             }
             part[wq][lane] = sw;
             part2[wq][lane] = sp;
-        }
-        if (send_down) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(&mflag[(size_t)K * MB_LD * 2 + MB_SEQ_DOWN], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         if (wq == 0) {
@@ -1006,12 +1016,12 @@ __global__ __launch_bounds__(64 * NW) void bc_stationary_kernel(int n, double *S
         }
         // the top row is finished (all of it was updated by this wavefront): it leaves for workgroup K - 1, or for memory
         if (wq == 0) {
-            const u32x4 rowv = pack2(Wn[ROW(0) + 2 * lane], Wn[ROW(0) + 2 * lane + 1]);
-            if (K == 0) __builtin_amdgcn_raw_buffer_store_b128(rowv, rsrc, (unsigned)((r0 * SB_LD + 2 * lane) * 8), 0, 0);
+            const double a_ = Wn[ROW(0) + 2 * lane], b_ = Wn[ROW(0) + 2 * lane + 1];
+            if (K == 0) __builtin_amdgcn_raw_buffer_store_b128(pack2(a_, b_), rsrc, (unsigned)((r0 * SB_LD + 2 * lane) * 8), 0, 0);
             else {
-                __builtin_amdgcn_raw_buffer_store_b128(rowv, rmail, (unsigned)((K * MB_LD + 2 * lane) * 8), 0, BC_SC1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(&mflag[(size_t)K * MB_LD * 2 + MB_SEQ_UP], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned tag = (unsigned)(s + 1), off = (unsigned)(K * MB_LD * 8 + 32 * lane);
+                __builtin_amdgcn_raw_buffer_store_b128(mb_pack(a_, tag), rmail, off, 0, BC_SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(mb_pack(b_, tag), rmail, off + 16, 0, BC_SC1);
             }
         }
         __syncthreads();

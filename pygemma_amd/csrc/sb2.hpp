@@ -7,7 +7,7 @@ namespace pg {
 constexpr int SB_B = 64;     // half-width of the band the first stage reduces to = reflector length of the second stage
 constexpr int SB_G = 64;     // sweeps per reflector block of the second stage's back-transformation
 constexpr int SB_LD = 2 * SB_B;   // row pitch of the compact band storage (band + room for the bulge)
-constexpr int SB_MAIL_LD = 256;   // doubles per workgroup mailbox of the stationary bulge-chasing kernel
+constexpr int SB_MAIL_LD = 512;   // doubles per workgroup mailbox of the stationary bulge-chasing kernel
 
 // work buffers of one solve; every pointer device memory, owned by the caller of sb2_alloc / sb2_free
 struct Sb2Work {
