@@ -1146,9 +1146,11 @@ __global__ __launch_bounds__(256) void bt2_prep_kernel(int n, int nk, int ng, co
 // lane l, component e = row (l >> 4) + 4 e, column l & 15) — which is also the layout of its B operand for the four k-steps of a
 // 16-row tile, so W = V' Zs needs no LDS copy of the slab, and the same registers are the C operand of the second product.
 // W (64 x 64) goes through LDS; V and V T (128 x 64 each, L2-resident: every slab of the block reads the same two) are staged in
-// chunks of 16 k-rows like dgemm's operands.  Four waves as 2 x 2; 76 KB of LDS: two workgroups per CU overlap each other's slab
-// traffic.  History at n = 10 000: two batched GEMMs per wavefront (40 MB of HBM traffic per block) 166 ms; fused with the slab in
-// LDS (one workgroup per CU, nothing overlapped) 142 ms; this version: see DESIGN.
+// chunks of 16 k-rows like dgemm's operands.  Four waves, one column tile of 16 each (all rows): the zero pattern of the
+// parallelogram (V has 64 non-zeros per column of 127) is then the same for every wave and known at compile time — 46 of the 64
+// tile products remain.  76 KB of LDS: two workgroups per CU overlap each other's slab traffic.  History at n = 10 000: two
+// batched GEMMs per wavefront (40 MB of HBM traffic per block) 166 ms; fused with the slab in LDS (one workgroup per CU, nothing
+// overlapped) 142 ms; slab in registers, waves as 2 x 2, all 64 tile products 102 ms; this version: see DESIGN.
 constexpr int BT2_NS = 64;                 // columns of Z per workgroup
 constexpr int BT2_ZP = BT2_NS + 16;        // LDS pitch of W: consecutive k-rows on disjoint bank halves (as in dgemm.hpp)
 constexpr int BT2_AP = 128 + 16;           // pitch of a staged operand chunk [CK][128]
@@ -1167,7 +1169,7 @@ __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
     extern __shared__ double lds[];
     double *Ws = lds;                               // [64][ZP]    Ws[sweep][c]
     double *As = Ws + 64 * BT2_ZP;                  // [2][CK][AP] operand chunk, k-major
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int z = blockIdx.y, n = ar.n;
     const long long row0 = ar.row_first + (long long)z * (B + SB_G);
     const int h = (z == ar.nb - 1) ? (int)ar.h_last : B + SB_G - 1;
@@ -1175,12 +1177,14 @@ __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
     const double *V = ar.Vp + (long long)z * ar.blk_stride, *Vt = ar.Vtp + (long long)z * ar.blk_stride;
     double *Zg = ar.Z + (size_t)row0 * n + c0;
     constexpr int CK = BT2_CK, NA = 128 / CK, NB2 = SB_G / CK;
-    // ---- slab in: this wave's 32 columns of all 128 rows (8 row tiles x 2 column tiles).  Full, 16-byte-aligned slabs come in whole
-    // rows (512 contiguous bytes, 16 per lane) through the operand staging space, 32 rows at a time, and are picked up from LDS in
-    // the accumulator layout; lane-wise 8-byte loads in that layout (64 per lane) were the slow part of the kernel (dgemm's epilogue
-    // had the same disease).  Edge slabs (last columns, odd n) keep the element-wise path.
-    doublex4 zr[8][2];
+    // ---- slab in.  Wavefront w owns column tile w (columns 16 w .. 16 w + 15) of the slab, all 128 rows, from here to the end:
+    // B operand of the first product, C operand and result of the second.  Full, 16-byte-aligned slabs come in whole rows (512
+    // contiguous bytes, 16 per lane) through the operand staging space, 32 rows at a time, and are picked up from LDS in the
+    // accumulator layout; lane-wise 8-byte loads in that layout were the slow part of the kernel (dgemm's epilogue had the same
+    // disease).  Edge slabs (last columns, odd n) keep the element-wise path.
+    doublex4 zr[8];
     const int rsub = lane >> 4, csub = lane & 15;
+    const int colw = wave * 16 + csub;              // this lane's column of the slab
     const bool vec = ar.vec && ncols == BT2_NS;
     constexpr int SP2 = BT2_NS + 8;                 // pitch of a staged slab row
     if (vec) {
@@ -1198,32 +1202,26 @@ __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
 #pragma unroll
             for (int tt = 0; tt < 2; tt++)
 #pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) zr[2 * ch + tt][j][e] = As[(16 * tt + rsub + 4 * e) * SP2 + wn * 32 + j * 16 + csub];
+                for (int e = 0; e < 4; e++) zr[2 * ch + tt][e] = As[(16 * tt + rsub + 4 * e) * SP2 + colw];
             __syncthreads();
         }
     } else {
 #pragma unroll
         for (int t = 0; t < 8; t++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int col = wn * 32 + j * 16 + csub;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int row = t * 16 + rsub + 4 * e;
-                    zr[t][j][e] = (row < h && col < ncols) ? Zg[(size_t)row * n + col] : 0.0;
-                }
+            for (int e = 0; e < 4; e++) {
+                const int row = t * 16 + rsub + 4 * e;
+                zr[t][e] = (row < h && colw < ncols) ? Zg[(size_t)row * n + colw] : 0.0;
             }
     }
-    // ---- phase A: W (64 sweeps x 64 columns) = V' Zs, K = 128 rows; operand chunk = CK rows of V (contiguous doubles)
-    doublex4 accA[2][2];
+    // ---- phase A: W (64 sweeps x 64 columns) = V' Zs, K = 128 rows; operand chunk = CK rows of V (contiguous doubles).
+    // Sweep tile I of V' is non-zero on the rows 16 I .. 16 I + 78 only (column i of V: rows i .. i + 63): row tiles I .. I + 4 of
+    // the eight — 20 tile products of 32; the others would add exact zeros.
+    doublex4 accA[4];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) accA[i][j][e] = 0.0;
+        for (int e = 0; e < 4; e++) accA[i][e] = 0.0;
     double2 stg[CK / 8];
     auto gloadA = [&](int kt) {      // chunk kt: rows CK kt ..: CK * 64 contiguous doubles; thread -> double2 number tid (+ 256 per pass)
 #pragma unroll
@@ -1237,6 +1235,7 @@ __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
             d[0] = stg[ps].x; d[1] = stg[ps].y;
         }
     };
+    static_assert(BT2_CK == 16, "the zero pattern below is per row tile of 16");
     gloadA(0);
     lstoreA(0);
     __syncthreads();
@@ -1247,33 +1246,22 @@ __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
 #pragma unroll
         for (int kk = 0; kk < CK; kk += 4) {
             const int kr = kk + rsub;
-            double a[2];
 #pragma unroll
-            for (int i = 0; i < 2; i++) a[i] = As[(buf * CK + kr) * BT2_AP + wm * 32 + i * 16 + csub];
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-                    accA[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], zr[(kt * CK + kk) / 16][j][((kt * CK + kk) % 16) / 4], accA[i][j], 0, 0, 0);
+            for (int I = 0; I < 4; I++) {
+                if (kt < I || kt > I + 4) continue;
+                accA[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(buf * CK + kr) * BT2_AP + I * 16 + csub], zr[kt][kk / 4], accA[I], 0, 0, 0);
+            }
         }
         if (kt + 1 < NA) lstoreA(buf ^ 1);
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int I = 0; I < 4; I++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                Ws[(wm * 32 + i * 16 + rsub + 4 * e) * BT2_ZP + wn * 32 + j * 16 + csub] = accA[i][j][e];
-    // ---- phase B: Zs (128 x 64) -= (V T) W, K = 64 sweeps; operand chunk = CK sweeps of all 128 rows of V T (row-major [row][sweep])
-    doublex4 accB[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) accB[i][j][e] = 0.0;
+        for (int e = 0; e < 4; e++) Ws[(I * 16 + rsub + 4 * e) * BT2_ZP + colw] = accA[I][e];
+    // ---- phase B: Zs (128 x 64) -= (V T) W, K = 64 sweeps, accumulated onto the slab registers themselves (V T enters negated);
+    // operand chunk = CK sweeps of all 128 rows of V T (row-major [row][sweep]).  Row tile R of V T is non-zero from sweep 16 R - 63
+    // on, i.e. on the sweep tiles max(0, R - 4) .. 3: 26 tile products of 32.
     double rt[CK / 8][4];
     auto gloadB = [&](int kt) {      // thread -> row tid / 2, 4 consecutive sweeps (+ 8 per pass)
 #pragma unroll
@@ -1299,47 +1287,25 @@ __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
 #pragma unroll
         for (int kk = 0; kk < CK; kk += 4) {
             const int kr = kk + rsub;
-            double a[4], b2[2];
+            const double b2 = Ws[(kt * CK + kr) * BT2_ZP + colw];
 #pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = As[(buf * CK + kr) * BT2_AP + wm * 64 + i * 16 + csub];
-#pragma unroll
-            for (int j = 0; j < 2; j++) b2[j] = Ws[(kt * CK + kr) * BT2_ZP + wn * 32 + j * 16 + csub];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) accB[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b2[j], accB[i][j], 0, 0, 0);
+            for (int R = 0; R < 8; R++) {
+                if (kt < R - 4) continue;
+                zr[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(-As[(buf * CK + kr) * BT2_AP + R * 16 + csub], b2, zr[R], 0, 0, 0);
+            }
         }
         if (kt + 1 < NB2) lstoreB(buf ^ 1);
         __syncthreads();
     }
-    // ---- slab out: this wave's rows 64 wm .. 64 wm + 63 (row tiles 4 wm + i of the registers)
-    auto store_rows = [&](auto WM) {
-        constexpr int wmc = decltype(WM)::value;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int col = wn * 32 + j * 16 + csub;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int row = wmc * 64 + i * 16 + rsub + 4 * e;
-                    if (row < h && col < ncols) Zg[(size_t)row * n + col] = zr[wmc * 4 + i][j][e] - accB[i][j][e];
-                }
-            }
-    };
+    // ---- slab out
     if (vec) {
-        // chunk ch = rows 32 ch ..: the waves of tile row ch / 2 put Zs - acc into the staging space, then everybody stores whole rows
-        auto stage_rows = [&](auto CH) {
-            constexpr int ch = decltype(CH)::value;
-            if (wm == (ch >> 1)) {
+        // chunk ch = rows 32 ch ..: into the staging space, then everybody stores whole rows
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++)
+        for (int ch = 0; ch < 4; ch++) {
 #pragma unroll
-                    for (int j = 0; j < 2; j++)
+            for (int tt = 0; tt < 2; tt++)
 #pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            As[(16 * tt + rsub + 4 * e) * SP2 + wn * 32 + j * 16 + csub] = zr[2 * ch + tt][j][e] - accB[2 * (ch & 1) + tt][j][e];
-            }
+                for (int e = 0; e < 4; e++) As[(16 * tt + rsub + 4 * e) * SP2 + colw] = zr[2 * ch + tt][e];
             __syncthreads();
 #pragma unroll
             for (int ps = 0; ps < 4; ps++) {
@@ -1348,13 +1314,16 @@ __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
                     *reinterpret_cast<double2 *>(Zg + (size_t)row * n + 2 * (tid & 31)) = *reinterpret_cast<const double2 *>(As + (8 * ps + (tid >> 5)) * SP2 + 2 * (tid & 31));
             }
             __syncthreads();
-        };
-        stage_rows(std::integral_constant<int, 0>{});
-        stage_rows(std::integral_constant<int, 1>{});
-        stage_rows(std::integral_constant<int, 2>{});
-        stage_rows(std::integral_constant<int, 3>{});
-    } else if (wm == 0) store_rows(std::integral_constant<int, 0>{});
-    else store_rows(std::integral_constant<int, 1>{});
+        }
+    } else {
+#pragma unroll
+        for (int R = 0; R < 8; R++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = R * 16 + rsub + 4 * e;
+                if (row < h && colw < ncols) Zg[(size_t)row * n + colw] = zr[R][e];
+            }
+    }
 }
 
 // the blocks (V, V T) of every (group, block index): needs only the reflectors, so the caller may run it on a second stream beside the

@@ -14,6 +14,6 @@ timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o 
 echo "trace done"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc -o c -- python3 $ROOT/tools/bench_syevd.py $N > $OUT/pmc.log 2>&1
 echo "pmc rc=$?"
-python3 $ROOT/tools/summarize_syevd.py $TAG $N
+python3 $ROOT/tools/summarize_syevd.py $TAG $N > $OUT/summary_head.txt && cp $ROOT/profiles/${TAG}_syevd_summary.json $OUT/   # profiles/ does not travel back, gpurun_out/ does
 find $OUT -name "*.db" -delete
 find $OUT -name "*.csv" -size +3M -delete
