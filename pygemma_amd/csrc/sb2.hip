@@ -1188,16 +1188,18 @@ __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
     const bool vec = ar.vec && ncols == BT2_NS;
     constexpr int SP2 = BT2_NS + 8;                 // pitch of a staged slab row
     if (vec) {
+        double2 cv[4][4];           // all 16 loads of the thread in flight at once: the memory latency is paid once per slab, not per chunk
 #pragma unroll
-        for (int ch = 0; ch < 4; ch++) {
-            double2 cv[4];
+        for (int ch = 0; ch < 4; ch++)
 #pragma unroll
             for (int ps = 0; ps < 4; ps++) {
                 const int row = 32 * ch + 8 * ps + (tid >> 5);
-                cv[ps] = (row < h) ? *reinterpret_cast<const double2 *>(Zg + (size_t)row * n + 2 * (tid & 31)) : make_double2(0.0, 0.0);
+                cv[ch][ps] = (row < h) ? *reinterpret_cast<const double2 *>(Zg + (size_t)row * n + 2 * (tid & 31)) : make_double2(0.0, 0.0);
             }
 #pragma unroll
-            for (int ps = 0; ps < 4; ps++) *reinterpret_cast<double2 *>(As + (8 * ps + (tid >> 5)) * SP2 + 2 * (tid & 31)) = cv[ps];
+        for (int ch = 0; ch < 4; ch++) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++) *reinterpret_cast<double2 *>(As + (8 * ps + (tid >> 5)) * SP2 + 2 * (tid & 31)) = cv[ch][ps];
             __syncthreads();
 #pragma unroll
             for (int tt = 0; tt < 2; tt++)
@@ -1326,6 +1328,188 @@ __global__ __launch_bounds__(256, 2) void bt2_apply_kernel(Bt2Args ar)
     }
 }
 
+// ---- four reflector blocks per pass ------------------------------------------------------------------------------------------------
+// bt2_apply_kernel moves a slab of Z through HBM once per block: 157 x (read + write) of Z at n = 10 000, 250 GB, and that — not
+// the MFMA work — sets its time.  Blocks (G, k), (G, k + 1), (G - 1, k), (G - 1, k + 1) lie on 255 consecutive rows (each block 127 rows,
+// starting 64 apart) and may be applied in exactly that order, so a workgroup that keeps 256 rows x 64 columns in registers applies all
+// four on ONE trip of the slab: half the traffic, a quarter of the launches' slab latencies.  The 2 x 2 super-blocks (u, ks) — groups
+// glast - 2u and glast - 2u - 1, block indices 2 ks and 2 ks + 1 — depend on each other exactly like the blocks do, so they run on
+// anti-diagonals u + ks = ts, their slabs 256 rows apart.  Same per-wave layout as above with 16 row tiles instead of 8.
+struct Bt2SArgs {
+    int n, ng, ts, u_first;
+    const double *Vp, *Vtp;       // block (G, k) at ((k ng + G) 128 x 64)
+    double *Z;
+    int vec;
+};
+__global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
+{
+    extern __shared__ double lds[];
+    double *Ws = lds;                               // [64][ZP]
+    double *As = Ws + 64 * BT2_ZP;                  // [2][CK][AP]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = ar.n, u = ar.u_first + blockIdx.y, ks = ar.ts - u;
+    const int Ghi = ar.ng - 1 - 2 * u, Glo = Ghi - 1, k0 = 2 * ks;
+    const long long a = (long long)Ghi * SB_G + 1 + (long long)k0 * B, slab0 = a - B;      // row of slab tile 0
+    auto exists = [&](int G, int k) { return G >= 0 && (long long)G * SB_G + 1 + (long long)k * B < n; };
+    const bool e0 = exists(Ghi, k0), e1 = exists(Ghi, k0 + 1), e2 = exists(Glo, k0), e3 = exists(Glo, k0 + 1);
+    if (!(e0 || e1 || e2 || e3)) return;
+    // rows of the slab any of the four touches (slab rows; tiles 0..7 | 4..11 | 4..11 | 8..15)
+    const int rlo = e2 ? 0 : ((e0 || e3) ? 64 : 128), rhi = e1 ? 256 : ((e0 || e3) ? 192 : 128);
+    const int c0 = blockIdx.x * BT2_NS, ncols = (n - c0 < BT2_NS) ? n - c0 : BT2_NS;
+    double *Zg = ar.Z + c0;                         // + grow * n
+    constexpr int CK = BT2_CK, NA = 128 / CK, NB2 = SB_G / CK;
+    constexpr size_t BLK = (size_t)128 * SB_G;
+    doublex4 zr[16];
+    const int rsub = lane >> 4, csub = lane & 15;
+    const int colw = wave * 16 + csub;
+    const bool vec = ar.vec && ncols == BT2_NS;
+    constexpr int SP2 = BT2_NS + 8;
+    auto row_ok = [&](int r) { const long long g = slab0 + r; return r >= rlo && r < rhi && g >= 0 && g < n; };
+    if (vec) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            double2 cv[4][4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+#pragma unroll
+                for (int ps = 0; ps < 4; ps++) {
+                    const int row = 128 * half + 32 * ch + 8 * ps + (tid >> 5);
+                    cv[ch][ps] = row_ok(row) ? *reinterpret_cast<const double2 *>(Zg + (size_t)(slab0 + row) * n + 2 * (tid & 31)) : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) {
+#pragma unroll
+                for (int ps = 0; ps < 4; ps++) *reinterpret_cast<double2 *>(As + (8 * ps + (tid >> 5)) * SP2 + 2 * (tid & 31)) = cv[ch][ps];
+                __syncthreads();
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) zr[8 * half + 2 * ch + tt][e] = As[(16 * tt + rsub + 4 * e) * SP2 + colw];
+                __syncthreads();
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; t++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = t * 16 + rsub + 4 * e;
+                zr[t][e] = (row_ok(row) && colw < ncols) ? Zg[(size_t)(slab0 + row) * n + colw] : 0.0;
+            }
+    }
+    // one block on the row tiles T0 .. T0 + 7 of the slab registers (the body of bt2_apply_kernel)
+    auto apply = [&](auto T0C, const double *V, const double *Vt) {
+        constexpr int T0 = decltype(T0C)::value;
+        doublex4 accA[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) accA[i][e] = 0.0;
+        double2 stg[CK / 8];
+        auto gloadA = [&](int kt) {
+#pragma unroll
+            for (int ps = 0; ps < CK / 8; ps++) stg[ps] = *reinterpret_cast<const double2 *>(V + (size_t)kt * CK * SB_G + 2 * (ps * 256 + tid));
+        };
+        auto lstoreA = [&](int buf) {
+#pragma unroll
+            for (int ps = 0; ps < CK / 8; ps++) {
+                const int e0_ = 2 * (ps * 256 + tid);
+                double *d = As + (buf * CK + (e0_ >> 6)) * BT2_AP + (e0_ & 63);
+                d[0] = stg[ps].x; d[1] = stg[ps].y;
+            }
+        };
+        gloadA(0);
+        lstoreA(0);
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < NA; kt++) {
+            const int buf = kt & 1;
+            if (kt + 1 < NA) gloadA(kt + 1);
+#pragma unroll
+            for (int kk = 0; kk < CK; kk += 4) {
+                const int kr = kk + rsub;
+#pragma unroll
+                for (int I = 0; I < 4; I++) {
+                    if (kt < I || kt > I + 4) continue;
+                    accA[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(buf * CK + kr) * BT2_AP + I * 16 + csub], zr[T0 + kt][kk / 4], accA[I], 0, 0, 0);
+                }
+            }
+            if (kt + 1 < NA) lstoreA(buf ^ 1);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int I = 0; I < 4; I++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) Ws[(I * 16 + rsub + 4 * e) * BT2_ZP + colw] = accA[I][e];
+        double rt[CK / 8][4];
+        auto gloadB = [&](int kt) {
+#pragma unroll
+            for (int ps = 0; ps < CK / 8; ps++) {
+                const double *src = Vt + (size_t)(tid >> 1) * SB_G + kt * CK + ps * 8 + (tid & 1) * 4;
+                const double2 x = *reinterpret_cast<const double2 *>(src), y = *reinterpret_cast<const double2 *>(src + 2);
+                rt[ps][0] = x.x; rt[ps][1] = x.y; rt[ps][2] = y.x; rt[ps][3] = y.y;
+            }
+        };
+        auto lstoreB = [&](int buf) {
+#pragma unroll
+            for (int ps = 0; ps < CK / 8; ps++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) As[(buf * CK + ps * 8 + (tid & 1) * 4 + q) * BT2_AP + (tid >> 1)] = rt[ps][q];
+        };
+        gloadB(0);
+        lstoreB(0);
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < NB2; kt++) {
+            const int buf = kt & 1;
+            if (kt + 1 < NB2) gloadB(kt + 1);
+#pragma unroll
+            for (int kk = 0; kk < CK; kk += 4) {
+                const int kr = kk + rsub;
+                const double b2 = Ws[(kt * CK + kr) * BT2_ZP + colw];
+#pragma unroll
+                for (int R = 0; R < 8; R++) {
+                    if (kt < R - 4) continue;
+                    zr[T0 + R] = __builtin_amdgcn_mfma_f64_16x16x4f64(-As[(buf * CK + kr) * BT2_AP + R * 16 + csub], b2, zr[T0 + R], 0, 0, 0);
+                }
+            }
+            if (kt + 1 < NB2) lstoreB(buf ^ 1);
+            __syncthreads();
+        }
+    };
+    const size_t ngs = (size_t)ar.ng;
+    if (e0) apply(std::integral_constant<int, 4>{}, ar.Vp + ((size_t)k0 * ngs + Ghi) * BLK, ar.Vtp + ((size_t)k0 * ngs + Ghi) * BLK);
+    if (e1) apply(std::integral_constant<int, 8>{}, ar.Vp + ((size_t)(k0 + 1) * ngs + Ghi) * BLK, ar.Vtp + ((size_t)(k0 + 1) * ngs + Ghi) * BLK);
+    if (e2) apply(std::integral_constant<int, 0>{}, ar.Vp + ((size_t)k0 * ngs + Glo) * BLK, ar.Vtp + ((size_t)k0 * ngs + Glo) * BLK);
+    if (e3) apply(std::integral_constant<int, 4>{}, ar.Vp + ((size_t)(k0 + 1) * ngs + Glo) * BLK, ar.Vtp + ((size_t)(k0 + 1) * ngs + Glo) * BLK);
+    // ---- slab out
+    if (vec) {
+#pragma unroll
+        for (int ch = 0; ch < 8; ch++) {
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) As[(16 * tt + rsub + 4 * e) * SP2 + colw] = zr[2 * ch + tt][e];
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++) {
+                const int row = 32 * ch + 8 * ps + (tid >> 5);
+                if (row_ok(row))
+                    *reinterpret_cast<double2 *>(Zg + (size_t)(slab0 + row) * n + 2 * (tid & 31)) = *reinterpret_cast<const double2 *>(As + (8 * ps + (tid >> 5)) * SP2 + 2 * (tid & 31));
+            }
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int R = 0; R < 16; R++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = R * 16 + rsub + 4 * e;
+                if (row_ok(row) && colw < ncols) Zg[(size_t)(slab0 + row) * n + colw] = zr[R][e];
+            }
+    }
+}
+
 // the blocks (V, V T) of every (group, block index): needs only the reflectors, so the caller may run it on a second stream beside the
 // divide & conquer (st = nullptr: the context's stream)
 int bt2_prep_device(pg_ctx *ctx, int n, Sb2Work &w, hipStream_t st)
@@ -1338,6 +1522,7 @@ int bt2_prep_device(pg_ctx *ctx, int n, Sb2Work &w, hipStream_t st)
     if (!attr_done) {
         PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS_BYTES));
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_apply4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS_BYTES));
         attr_done = true;
     }
     bt2_prep_kernel<<<dim3(w.ng, w.kmax), 256, lds, st>>>(n, w.nk, w.ng, w.VV, w.TAU, w.Vp, w.Vtp);
@@ -1355,6 +1540,20 @@ int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w, bool prepared)
     const size_t blk = (size_t)VR * SB_G;
     const int glast = ng - 1;
     const int nslab = (n + BT2_NS - 1) / BT2_NS;
+    bool four = true;       // four blocks per trip of a slab (bt2_apply4_kernel); PG_BT2_FOUR=0: one block per trip
+    if (const char *e_ = getenv("PG_BT2_FOUR")) four = atoi(e_) != 0;
+    if (four) {
+        const int nu = (ng + 1) / 2, kcount = (n - 1 + B - 1) / B, nks = (kcount + 1) / 2;
+        for (int ts = 0; ts <= (nu - 1) + (nks - 1); ts++) {
+            const int u_lo = std::max(0, ts - (nks - 1)), u_hi = std::min(ts, nu - 1);
+            Bt2SArgs ar;
+            ar.n = n; ar.ng = ng; ar.ts = ts; ar.u_first = u_lo; ar.Vp = w.Vp; ar.Vtp = w.Vtp; ar.Z = Z;
+            ar.vec = ((n & 1) == 0 && (uintptr_t)Z % 16 == 0) ? 1 : 0;
+            bt2_apply4_kernel<<<dim3(nslab, u_hi - u_lo + 1), 256, BT2_LDS_BYTES, st>>>(ar);
+        }
+        PG_HIP(hipGetLastError());
+        return PG_OK;
+    }
     // wavefront t: blocks (G, k) with (glast - G) + k = t; their rows start (g + b) apart
     for (int t = 0;; t++) {
         const int kmin = std::max(0, t - glast);
