@@ -1397,7 +1397,9 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
                 zr[t][e] = (row_ok(row) && colw < ncols) ? Zg[(size_t)(slab0 + row) * n + colw] : 0.0;
             }
     }
-    // one block on the row tiles T0 .. T0 + 7 of the slab registers (the body of bt2_apply_kernel)
+    // one block on the row tiles T0 .. T0 + 7 of the slab registers (the body of bt2_apply_kernel).  Operand chunks are fetched TWO
+    // steps ahead (a step is 8 - 16 MFMAs, 0.2 - 0.4 us: less than an L2 round trip), the first two chunks of the second product
+    // during the last two steps of the first.
     auto apply = [&](auto T0C, const double *V, const double *Vt) {
         constexpr int T0 = decltype(T0C)::value;
         doublex4 accA[4];
@@ -1405,26 +1407,43 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int e = 0; e < 4; e++) accA[i][e] = 0.0;
-        double2 stg[CK / 8];
-        auto gloadA = [&](int kt) {
+        double2 stg[2][CK / 8];
+        double rt[2][CK / 8][4];
+        auto gloadA = [&](int kt, int set) {
 #pragma unroll
-            for (int ps = 0; ps < CK / 8; ps++) stg[ps] = *reinterpret_cast<const double2 *>(V + (size_t)kt * CK * SB_G + 2 * (ps * 256 + tid));
+            for (int ps = 0; ps < CK / 8; ps++) stg[set][ps] = *reinterpret_cast<const double2 *>(V + (size_t)kt * CK * SB_G + 2 * (ps * 256 + tid));
         };
-        auto lstoreA = [&](int buf) {
+        auto lstoreA = [&](int buf, int set) {
 #pragma unroll
             for (int ps = 0; ps < CK / 8; ps++) {
                 const int e0_ = 2 * (ps * 256 + tid);
                 double *d = As + (buf * CK + (e0_ >> 6)) * BT2_AP + (e0_ & 63);
-                d[0] = stg[ps].x; d[1] = stg[ps].y;
+                d[0] = stg[set][ps].x; d[1] = stg[set][ps].y;
             }
         };
-        gloadA(0);
-        lstoreA(0);
+        auto gloadB = [&](int kt, int set) {
+#pragma unroll
+            for (int ps = 0; ps < CK / 8; ps++) {
+                const double *src = Vt + (size_t)(tid >> 1) * SB_G + kt * CK + ps * 8 + (tid & 1) * 4;
+                const double2 x = *reinterpret_cast<const double2 *>(src), y = *reinterpret_cast<const double2 *>(src + 2);
+                rt[set][ps][0] = x.x; rt[set][ps][1] = x.y; rt[set][ps][2] = y.x; rt[set][ps][3] = y.y;
+            }
+        };
+        auto lstoreB = [&](int buf, int set) {
+#pragma unroll
+            for (int ps = 0; ps < CK / 8; ps++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) As[(buf * CK + ps * 8 + (tid & 1) * 4 + q) * BT2_AP + (tid >> 1)] = rt[set][ps][q];
+        };
+        gloadA(0, 0);
+        gloadA(1, 1);
+        lstoreA(0, 0);
         __syncthreads();
 #pragma unroll
         for (int kt = 0; kt < NA; kt++) {
             const int buf = kt & 1;
-            if (kt + 1 < NA) gloadA(kt + 1);
+            if (kt + 2 < NA) gloadA(kt + 2, kt & 1);            // set kt & 1 went to LDS one step ago
+            else gloadB(kt + 2 - NA, (kt + 2 - NA) & 1);
 #pragma unroll
             for (int kk = 0; kk < CK; kk += 4) {
                 const int kr = kk + rsub;
@@ -1434,35 +1453,19 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
                     accA[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(buf * CK + kr) * BT2_AP + I * 16 + csub], zr[T0 + kt][kk / 4], accA[I], 0, 0, 0);
                 }
             }
-            if (kt + 1 < NA) lstoreA(buf ^ 1);
+            if (kt + 1 < NA) lstoreA(buf ^ 1, (kt + 1) & 1);
             __syncthreads();
         }
 #pragma unroll
         for (int I = 0; I < 4; I++)
 #pragma unroll
             for (int e = 0; e < 4; e++) Ws[(I * 16 + rsub + 4 * e) * BT2_ZP + colw] = accA[I][e];
-        double rt[CK / 8][4];
-        auto gloadB = [&](int kt) {
-#pragma unroll
-            for (int ps = 0; ps < CK / 8; ps++) {
-                const double *src = Vt + (size_t)(tid >> 1) * SB_G + kt * CK + ps * 8 + (tid & 1) * 4;
-                const double2 x = *reinterpret_cast<const double2 *>(src), y = *reinterpret_cast<const double2 *>(src + 2);
-                rt[ps][0] = x.x; rt[ps][1] = x.y; rt[ps][2] = y.x; rt[ps][3] = y.y;
-            }
-        };
-        auto lstoreB = [&](int buf) {
-#pragma unroll
-            for (int ps = 0; ps < CK / 8; ps++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) As[(buf * CK + ps * 8 + (tid & 1) * 4 + q) * BT2_AP + (tid >> 1)] = rt[ps][q];
-        };
-        gloadB(0);
-        lstoreB(0);
+        lstoreB(0, 0);
         __syncthreads();
 #pragma unroll
         for (int kt = 0; kt < NB2; kt++) {
             const int buf = kt & 1;
-            if (kt + 1 < NB2) gloadB(kt + 1);
+            if (kt + 2 < NB2) gloadB(kt + 2, kt & 1);
 #pragma unroll
             for (int kk = 0; kk < CK; kk += 4) {
                 const int kr = kk + rsub;
@@ -1473,7 +1476,7 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
                     zr[T0 + R] = __builtin_amdgcn_mfma_f64_16x16x4f64(-As[(buf * CK + kr) * BT2_AP + R * 16 + csub], b2, zr[T0 + R], 0, 0, 0);
                 }
             }
-            if (kt + 1 < NB2) lstoreB(buf ^ 1);
+            if (kt + 1 < NB2) lstoreB(buf ^ 1, (kt + 1) & 1);
             __syncthreads();
         }
     };
