@@ -122,6 +122,25 @@ __device__ void mm64(FA a, FB b, OUT out, int tid)
     for (int q = 0; q < 16; q++) out(i, j0 + q, acc[q]);
 }
 
+// C = A Bm (64 x 64 x 64, operands in LDS, row-major, pitch P65) on the fp64 MFMA: wavefront w computes rows 16 w .. 16 w + 15 (four
+// 16 x 16 tiles); acc[tj][e] = C[16 w + (lane >> 4) + 4 e][16 tj + (lane & 15)].  (The scalar-FMA version mm64 spent 28 us of a
+// lone workgroup's time per product — LDS latency, 17 reads per 16 FMAs — where this one needs 5 reads per 4 MFMAs.)
+__device__ __forceinline__ void mm64_mfma(const double *A, const double *Bm, doublex4 (&acc)[4], int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[tj][e] = 0.0;
+#pragma unroll 4
+    for (int ks = 0; ks < B / 4; ks++) {
+        const double a = A[(16 * wave + r16) * P65 + 4 * ks + k4];
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+            acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bm[(4 * ks + k4) * P65 + 16 * tj + r16], acc[tj], 0, 0, 0);
+    }
+}
+
 __device__ __forceinline__ void load64(double *dst, const double *src, long long ld, int tid)
 {
     const int i = tid >> 2, j0 = (tid & 3) * 16;
@@ -144,6 +163,56 @@ __device__ __forceinline__ void solve_rows_wave(double *X, UC ucoef, UD urcp, RH
         }
         for (; k < j; k++) s0 = fma(X[lane * P65 + k], ucoef(k, j), s0);
         X[lane * P65 + j] = (rhs(lane, j) - ((s0 + s1) + (s2 + s3))) * urcp(j);
+    }
+}
+
+// X C = R for X in place (X holds R on entry; LDS, pitch P65), C upper triangular with coef(k, j) = C[k][j] (k < j) and
+// rcp(j) = 1 / C[j][j], by ONE wavefront, in column blocks of 16: the part of the right-hand side that earlier blocks determine
+// is an fp64-MFMA product (A operand = the finished columns of X, B operand = C through the accessor), the 16 x 16 triangle is
+// solved with lane = row, the row's 16 unknowns in registers and the coefficients broadcast from LDS — 480 dependent terms per
+// lane instead of the 2016 of solve_rows_wave (43 us for the two solves of recon_kernel, its largest part).
+template <class UC, class UD>
+__device__ __forceinline__ void solve_rows_blocked(double *X, UC coef, UD rcp, int lane)
+{
+    const int r16 = lane & 15, k4 = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        if (b > 0) {
+            doublex4 acc[4];
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) acc[ti][e] = X[(16 * ti + k4 + 4 * e) * P65 + 16 * b + r16];
+#pragma unroll
+            for (int ks = 0; ks < 4 * b; ks++) {
+                const double cb = coef(4 * ks + k4, 16 * b + r16);
+#pragma unroll
+                for (int ti = 0; ti < 4; ti++)
+                    acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[(16 * ti + r16) * P65 + 4 * ks + k4], cb, acc[ti], 0, 0, 0);
+            }
+            wave_sync_lds();
+#pragma unroll
+            for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) X[(16 * ti + k4 + 4 * e) * P65 + 16 * b + r16] = acc[ti][e];
+            wave_sync_lds();
+        }
+        double x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = X[lane * P65 + 16 * b + j];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < j; k++) {
+                if (k & 1) s1 = fma(x[k], coef(16 * b + k, 16 * b + j), s1);
+                else s0 = fma(x[k], coef(16 * b + k, 16 * b + j), s0);
+            }
+            x[j] = (x[j] - (s0 + s1)) * rcp(16 * b + j);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) X[lane * P65 + 16 * b + j] = x[j];
+        wave_sync_lds();
     }
 }
 
@@ -173,26 +242,25 @@ __global__ __launch_bounds__(64) void chol_inv_kernel(const double *G, double *R
         for (int i = k + 1; i < B; i++) a[i] = fma(-readlane_d(rk, i), rk, a[i]);   // A[i][lane] -= R[k][i] R[k][lane]  (used for lane >= i)
     }
     if (!ok && lane == 0) atomicOr(fail, 1);
-    // X R = I: lane = row i of X;  R[k][j] = lane j's a[k]
-    double x[B];
+    // X R = I through LDS (blocked: solve_rows_blocked; the register version — 2016 dependent v_readlane + FMA pairs — took as long
+    // as the factorisation itself)
+    extern __shared__ double lds[];
+    double *Rm = lds, *Xl = lds + MAT, *rcs = lds + 2 * MAT;
 #pragma unroll
-    for (int j = 0; j < B; j++) {
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < j; k++) {
-            if (k & 1) s1 = fma(x[k], readlane_d(a[k], j), s1);
-            else s0 = fma(x[k], readlane_d(a[k], j), s0);
-        }
-        x[j] = (((lane == j) ? 1.0 : 0.0) - (s0 + s1)) * rc[j];
+    for (int i = 0; i < B; i++) {
+        const double r = (lane >= i) ? a[i] : 0.0;
+        Rm[i * P65 + lane] = r;
+        R[i * B + lane] = r;
+        Xl[i * P65 + lane] = (i == lane) ? 1.0 : 0.0;
     }
+    if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < B; i++) R[i * B + lane] = (lane >= i) ? a[i] : 0.0;
-    extern __shared__ double lds[];                      // transpose X through LDS for coalesced stores
-#pragma unroll
-    for (int j = 0; j < B; j++) lds[lane * P65 + j] = (j >= lane) ? x[j] : 0.0;
+        for (int k = 0; k < B; k++) rcs[k] = rc[k];
+    }
     wave_sync_lds();
+    solve_rows_blocked(Xl, [&](int k, int j) { return Rm[k * P65 + j]; }, [&](int j) { return rcs[j]; }, lane);
 #pragma unroll
-    for (int i = 0; i < B; i++) Rinv[i * B + lane] = lds[i * P65 + lane];
+    for (int i = 0; i < B; i++) Rinv[i * B + lane] = (lane >= i) ? Xl[i * P65 + lane] : 0.0;
 }
 
 // ---- pass 2 + Householder reconstruction ------------------------------------------------------------------------------------
@@ -212,6 +280,13 @@ __global__ __launch_bounds__(256) void recon_kernel(const double *G2, const doub
     __shared__ double Dg[B], piv[B], prc[B];
     __shared__ double red[4];
     const int tid = threadIdx.x, i = tid >> 2, j0 = (tid & 3) * 16, lane = tid & 63, wave = tid >> 6;
+#ifdef PG_RECON_TIME
+    long long tk[8]; int nt = 0;
+#define RT_MARK() do { __syncthreads(); tk[nt++] = wall_clock64(); } while (0)
+    RT_MARK();
+#else
+#define RT_MARK() do { } while (0)
+#endif
     // orthogonality of pass 1 = |G2 - I|_max: CholeskyQR2 reaches working accuracy when this is well below 1
     double err = 0.0;
 #pragma unroll
@@ -244,53 +319,71 @@ __global__ __launch_bounds__(256) void recon_kernel(const double *G2, const doub
         solve_right_upper64(M1, [&](int k, int j) { return M0[k * P65 + j]; }, [&](int j) { return M0[j * P65 + j]; },
                             [&](int a, int b) { return a == b ? 1.0 : 0.0; }, tid);   // M1 = R2^-1
     }
-    mm64([&](int a, int k) { return M0[a * P65 + k]; }, [&](int k, int b) { return M2[k * P65 + b]; },
-         [&](int a, int b, double v) { Rprod[a * B + b] = v; }, tid);              // R2 R1 (scaled by D on the way out)
+    RT_MARK();
+    {
+        doublex4 acc[4];
+        mm64_mfma(M0, M2, acc, tid);                                              // R2 R1 (scaled by D on the way out, by whoever reads it)
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) Rprod[(16 * wave + (lane >> 4) + 4 * e) * B + 16 * tj + (lane & 15)] = acc[tj][e];
+    }
     __syncthreads();                                                              // R1 is done with: M2 takes the top block of Q
-    load64(M2, Q1top, B, tid);                                                    // Q1's top block through LDS (it was read from global inside the product)
+    load64(M2, Q1top, B, tid);                                                    // Q1's top block through LDS
     __syncthreads();
     {
-        double qv[16];
-        mm64([&](int a, int k) { return M2[a * P65 + k]; }, [&](int k, int b) { return M1[k * P65 + b]; },
-             [&](int, int b, double v) { qv[b & 15] = v; }, tid);
+        doublex4 acc[4];
+        mm64_mfma(M2, M1, acc, tid);
         __syncthreads();                                                          // every read of Q1's top block is done
 #pragma unroll
-        for (int q = 0; q < 16; q++) M2[i * P65 + j0 + q] = qv[q];                  // M2 = top block of Q = Q1 R2^-1
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) M2[(16 * wave + (lane >> 4) + 4 * e) * P65 + 16 * tj + (lane & 15)] = acc[tj][e];   // M2 = top block of Q = Q1 R2^-1
     }
     __syncthreads();
+    RT_MARK();
     // LU of E - Q D without pivoting on the top block: ONE wavefront, the matrix in registers (lane j = column j), right-looking with
     // compile-time lane numbers (v_readlane) — no LDS traffic, no barriers inside the 64 steps.  After step k row k holds the
     // eliminated entries W[k][j] = q~_j[k] of Q for j >= k (U[k][j] = -D_j W[k][j], U[k][k] = piv_k = 1 + |W[k][k]|), column k the
     // multipliers L[r][k], r > k (= V's top block).  (Crout order on two wavefronts with three workgroup barriers per step: 222 us
     // for the whole kernel; the first version, rank-one updates by the whole workgroup: 320.)
     if (wave == 0) {
+        // lane = ROW r, m[c] = entry (r, c).  Step k: lane k holds row k (W[k][c], c >= k); every lane below multiplies its entry of
+        // column k by -D_k / pivot (its multiplier L[r][k], left in m[k]) and subtracts L[r][k] W[k][c] from the rest of its row —
+        // W[k][c] by v_readlane from lane k, one FMA per entry, lanes at or above k neutralised by a zero multiplier.
         double m[B];
 #pragma unroll
-        for (int r = 0; r < B; r++) m[r] = M2[r * P65 + lane];
+        for (int c = 0; c < B; c++) m[c] = M2[lane * P65 + c];
 #pragma unroll
         for (int k = 0; k < B; k++) {
             const double wkk = readlane_d(m[k], k);
             const double dk = (wkk >= 0.0) ? -1.0 : 1.0, pv = 1.0 - dk * wkk, rc = 1.0 / pv, sc = -dk * rc;
             if (lane == 0) { Dg[k] = dk; piv[k] = pv; prc[k] = rc; }
-            const double mk = m[k];                              // W[k][lane]
+            const double l = (lane > k) ? m[k] * sc : 0.0;       // L[lane][k]
 #pragma unroll
-            for (int r = k + 1; r < B; r++) {
-                const double l = readlane_d(m[r], k) * sc;       // L[r][k]
-                m[r] = (lane > k) ? fma(-l, mk, m[r]) : ((lane == k) ? l : m[r]);
-            }
+            for (int c = k + 1; c < B; c++) m[c] = fma(-l, readlane_d(m[c], k), m[c]);
+            if (lane > k) m[k] = l;
         }
 #pragma unroll
-        for (int r = 0; r < B; r++) M2[r * P65 + lane] = m[r];
+        for (int c = 0; c < B; c++) M2[lane * P65 + c] = m[c];
     }
     __syncthreads();
+    RT_MARK();
     // T = U Y1^-T: T Y1' = U, Y1' unit upper triangular with Y1'[k][j] = L[j][k]  (wave 0 -> M0);  Xm U = -R2^-1 D  (wave 1, in place on M1)
-    if (wave == 0)
-        solve_rows_wave(M0, [&](int k, int j) { return M2[j * P65 + k]; }, [&](int) { return 1.0; },
-                        [&](int a, int b) { return (a == b) ? piv[b] : ((a < b) ? -Dg[b] * M2[a * P65 + b] : 0.0); }, lane);
-    else if (wave == 1)      // in place on M1: a lane reads the right-hand side of its own row at (a, b) just before it writes X[a][b] there
-        solve_rows_wave(M1, [&](int k, int j) { return -Dg[j] * M2[k * P65 + j]; }, [&](int j) { return prc[j]; },
-                        [&](int a, int b) { return -M1[a * P65 + b] * Dg[b]; }, lane);
+    if (wave == 0) {
+        for (int c = 0; c < B; c++) M0[lane * P65 + c] = (lane == c) ? piv[c] : ((lane < c) ? -Dg[c] * M2[lane * P65 + c] : 0.0);    // U
+        wave_sync_lds();
+        solve_rows_blocked(M0, [&](int k, int j) { return M2[j * P65 + k]; }, [&](int) { return 1.0; }, lane);
+    } else if (wave == 1) {
+        for (int c = 0; c < B; c++) M1[lane * P65 + c] = -M1[lane * P65 + c] * Dg[c];
+        wave_sync_lds();
+        solve_rows_blocked(M1, [&](int k, int j) { return -Dg[j] * M2[k * P65 + j]; }, [&](int j) { return prc[j]; }, lane);
+    }
     __syncthreads();
+    RT_MARK();
+#ifdef PG_RECON_TIME
+    if (tid == 0) printf("recon ticks(10ns): load+R2 %lld | 2 products %lld | LU %lld | solves %lld\n", tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3]);
+#endif
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int c = j0 + q;
@@ -447,12 +540,12 @@ void sb2_free(Sb2Work &w)
 int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
 {
     hipStream_t st = ctx->stream;
-    constexpr int LDS4 = 4 * MAT * 8;
+    constexpr int LDS4 = 4 * MAT * 8, CHOL_LDS = (2 * MAT + B) * 8;
     static bool attr_done = false;
     if (!attr_done) {
         PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recon_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
         PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
-        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MAT * 8));
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CHOL_LDS));
         attr_done = true;
     }
     PG_HIP(hipMemsetAsync(w.Vst, 0, (size_t)n * n * 8, st));
@@ -483,7 +576,7 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
             // CholeskyQR2: G1 = P'P, R1; Q1 = P R1^-1; G2 = Q1'Q1, R2; (Q = Q1 R2^-1 only through its top block and Xm)
             rc = dgemm(c, true, B, B, m, 1.0, P, ld, P, ld, 0.0, SM(SM_G1), B);
             if (rc) return rc;
-            chol_inv_kernel<<<1, 64, MAT * 8, cs>>>(SM(SM_G1), SM(SM_R1), SM(SM_R1INV), w.fail);
+            chol_inv_kernel<<<1, 64, CHOL_LDS, cs>>>(SM(SM_G1), SM(SM_R1), SM(SM_R1INV), w.fail);
             rc = dgemm(c, false, m, B, B, 1.0, P, ld, SM(SM_R1INV), B, 0.0, Qb0, B);
             if (!rc) rc = dgemm(c, true, B, B, m, 1.0, Qb0, B, Qb0, B, 0.0, SM(SM_G2), B);
             if (rc) return rc;
@@ -498,24 +591,27 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
         PG_HIP(hipGetLastError());
         return PG_OK;
     };
-    // Look-ahead (opt-in: PG_SB2_LOOKAHEAD=1): the rank-128 update of panel j is issued as its first tile column (which holds the next
-    // panel) and the rest; the next panel's factorisation — a chain of single-workgroup kernels and small GEMMs, ~250 us of mostly idle
-    // chip — runs on a second, high-priority stream beside the rest.  [V W] is read by the update from its transposed copy, so the
-    // factorisation may overwrite V, Q and the small matrices at once; it has its own split-K work space (the context copy below).
-    // Measured at n = 10 000: the two do run side by side (kernel trace), but the latency chain slows down by what it hides — its single
-    // wavefronts share SIMDs with the update's MFMA waves: Cholesky 61 -> 145 us, reconstruction 182 -> 205 us, with or without
-    // s_setprio — and the phase stays at 116 ms (118.7 without).  Off by default: one stream, nothing to go wrong.
+    // Look-ahead (opt-in: PG_SB2_LOOKAHEAD=<CUs to reserve>): the rank-128 update of panel j is issued as its first tile column (which
+    // holds the next panel) and the rest; the rest runs on a second stream whose CU mask leaves some CUs out, the next panel's
+    // factorisation — a chain of single-workgroup kernels and small GEMMs, ~300 us of mostly idle chip — follows the first tile column
+    // on the caller's stream.  [V W] is read by the update from its transposed copy, so the factorisation may overwrite V, Q and the
+    // small matrices at once.  (First version: the factorisation on a high-priority stream beside an unmasked update.  The two did
+    // run side by side, but the chain's single wavefronts shared SIMDs with the update's MFMA waves and slowed down by what they hid:
+    // Cholesky 61 -> 145 us, reconstruction 182 -> 205 us, phase 116 ms against 118.7.)
     pg_ctx side = *ctx;
     side.scratch = nullptr; side.scratch_bytes = 0; side.stream = nullptr;
     hipEvent_t e_col = nullptr, e_fac = nullptr;
-    int prio_lo = 0, prio_hi = 0;
     bool ahead = false;
-    if (getenv("PG_SB2_LOOKAHEAD")) {
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // the factorisation's small workgroups take freed CU slots first
-        ahead = hipStreamCreateWithPriority(&side.stream, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+    if (const char *e_ = getenv("PG_SB2_LOOKAHEAD")) {
+        const int reserve = std::max(1, std::min(atoi(e_), ctx->num_cu / 2));
+        uint32_t mask[16];
+        const int words = (ctx->num_cu + 31) / 32;
+        for (int q = 0; q < 16; q++) mask[q] = 0;
+        for (int c = reserve; c < ctx->num_cu; c++) mask[c / 32] |= 1u << (c % 32);
+        ahead = words <= 16 && hipExtStreamCreateWithCUMask(&side.stream, (uint32_t)words, mask) == hipSuccess &&
                 hipEventCreateWithFlags(&e_col, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e_fac, hipEventDisableTiming) == hipSuccess;
+        if (!ahead) (void)hipGetLastError();
     }
-    if (!getenv("PG_SB2_LOOKAHEAD")) ahead = false;
     auto finish = [&](int rc) {
         if (side.stream) { (void)hipStreamSynchronize(side.stream); (void)hipStreamDestroy(side.stream); }
         if (e_col) (void)hipEventDestroy(e_col);
@@ -555,25 +651,29 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
         DgemmDesc d;
         d.transA = true; d.kxorB = B; d.K = 2 * B; d.alpha = -1.0; d.beta = 1.0; d.lower_only = true; d.lda = ldt; d.ldb = ldt; d.ldc = ld;
         const bool split = ahead && next && mm > 128;
+        factored = false;
+        if (split) {
+            // the part of the update beyond the first tile column: on the masked stream, as soon as [V W]' is there
+            if (hipEventRecord(e_col, st) != hipSuccess) return finish(PG_EHIP);
+            if (hipStreamWaitEvent(side.stream, e_col, 0) != hipSuccess) return finish(PG_EHIP);
+            d.M = mm - 128; d.N = mm - 128;
+            d.A = VWt + 128 - pad + 128; d.B = d.A; d.C = A22al + (size_t)128 * ld + 128;
+            rc = dgemm_ex(&side, d);
+            if (rc) return finish(rc);
+            if (hipEventRecord(e_fac, side.stream) != hipSuccess) return finish(PG_EHIP);
+        }
         d.M = mm; d.N = split ? 128 : mm;
         d.A = VWt + 128 - pad; d.B = d.A; d.C = A22al;
         rc = dgemm_ex(ctx, d);
         if (rc) return finish(rc);
-        factored = false;
         if (split) {
-            // host order matters: the rest of the update is enqueued first (the chip must have it to run beside the factorisation)
-            if (hipEventRecord(e_col, st) != hipSuccess) return finish(PG_EHIP);
-            d.M = mm - 128; d.N = mm - 128;
-            d.A = VWt + 128 - pad + 128; d.B = d.A; d.C = A22al + (size_t)128 * ld + 128;
-            rc = dgemm_ex(ctx, d);
+            // the next panel's factorisation behind the first tile column, beside the rest
+            rc = factor(ctx, j + B, pan + 1);
             if (rc) return finish(rc);
-            if (hipStreamWaitEvent(side.stream, e_col, 0) != hipSuccess) return finish(PG_EHIP);
-            rc = factor(&side, j + B, pan + 1);
-            if (rc) return finish(rc);
-            if (hipEventRecord(e_fac, side.stream) != hipSuccess) return finish(PG_EHIP);
             factored = true;
         }
     }
+    if (factored && hipStreamWaitEvent(st, e_fac, 0) != hipSuccess) return finish(PG_EHIP);
     return finish(PG_OK);
 }
 
