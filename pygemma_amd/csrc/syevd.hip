@@ -1209,7 +1209,8 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
 }
 
 #ifndef PG_SYEVD2_MIN_N
-#define PG_SYEVD2_MIN_N 3584     // below this the one-stage reduction is as fast or faster (profiles/r03_other_sizes.txt: n = 3 000: 84 vs 83 ms; 4 096: 123 vs 117; 6 000: 223 vs 194; 10 000: 585 vs 461)
+#define PG_SYEVD2_MIN_N 1536     // profiles/r03_other_sizes.txt, second call: the two-stage path is ahead from n ~ 600 on (768: 18 vs 20 ms; 1 940: 38 vs 52;
+                                 // 10 000: 330 vs 588); a process's first solve pays ~10 ms more for it (more kernels to load), even at n ~ 1 500
 #endif
 #ifndef PG_SYEVD2_MAX_N
 #define PG_SYEVD2_MAX_N 24000    // work space of the two-stage path ~ 12 n^2 doubles
