@@ -1187,7 +1187,7 @@ __global__ __launch_bounds__(256) void bt2_prep_kernel(int n, int nk, int ng, co
     double *Gm = lds + VR * P65;        // [64][65]
     double *Tm = Gm + MAT;              // [64][65]
     __shared__ double tau[SB_G];
-    const int G = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+    const int G = blockIdx.x, k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
     const int s0 = G * SB_G, row0 = s0 + 1 + k * B;
     if (row0 >= n) return;
     const size_t blk = ((size_t)k * ng + G) * VR * SB_G;
@@ -1202,42 +1202,51 @@ __global__ __launch_bounds__(256) void bt2_prep_kernel(int n, int nk, int ng, co
     if (tid < SB_G) {
         const int s = s0 + tid;
         tau[tid] = (s <= n - 3 && s + 1 + k * B < n) ? TAU[(size_t)s * nk + k] : 0.0;
-        for (int j = 0; j < SB_G; j++) Tm[tid * P65 + j] = 0.0;
     }
+    for (int idx = tid; idx < SB_G * SB_G; idx += 256) Tm[(idx >> 6) * P65 + (idx & 63)] = ((idx >> 6) == (idx & 63)) ? 1.0 : 0.0;
     __syncthreads();
-    {   // Gram (upper part is what the recurrence reads)
-        const int i = tid >> 2, j0 = (tid & 3) * 16;
-        double acc[16];
+    {   // Gram G = V'V on the MFMA (K = 128 rows): wavefront w its sweeps 16 w .. 16 w + 15
+        doublex4 acc[4];
 #pragma unroll
-        for (int q = 0; q < 16; q++) acc[q] = 0.0;
-        for (int r = 0; r < VR; r++) {
-            const double a = V[r * P65 + i];
+        for (int tj = 0; tj < 4; tj++)
 #pragma unroll
-            for (int q = 0; q < 16; q++) acc[q] = fma(a, V[r * P65 + j0 + q], acc[q]);
+            for (int e = 0; e < 4; e++) acc[tj][e] = 0.0;
+#pragma unroll 4
+        for (int ks = 0; ks < VR / 4; ks++) {
+            const double a = V[(4 * ks + k4) * P65 + 16 * wave + r16];
+#pragma unroll
+            for (int tj = 0; tj < 4; tj++) acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[(4 * ks + k4) * P65 + 16 * tj + r16], acc[tj], 0, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 16; q++) Gm[i * P65 + j0 + q] = acc[q];
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) Gm[(16 * wave + k4 + 4 * e) * P65 + 16 * tj + r16] = acc[tj][e];
     }
     __syncthreads();
-    for (int j = 0; j < SB_G; j++) {
-        const double tj = tau[j];
-        double v = 0.0;
-        if (tid < j) {
-            for (int l = tid; l < j; l++) v = fma(Tm[tid * P65 + l], Gm[l * P65 + j], v);
-            v *= -tj;
+    // T (forward, columnwise: T[i][j] = -tau_j sum_{l=i}^{j-1} T[i][l] G[l][j], T[j][j] = tau_j) is the inverse of the upper triangular
+    // matrix with diagonal 1 / tau_j and G above it: X M = I by the blocked row solve, rcp(j) = tau_j (a reflector with tau = 0 gets
+    // its zero row and column).  The 64-step recurrence with two workgroup barriers per step was most of this kernel's 11 ms.
+    if (wave == 0) solve_rows_blocked(Tm, [&](int kk, int j) { return Gm[kk * P65 + j]; }, [&](int j) { return tau[j]; }, lane);
+    __syncthreads();
+    // V and V T out (row-major 128 x 64); V T on the MFMA: wavefront w the rows 32 w .. 32 w + 31
+    for (int idx = tid; idx < VR * SB_G; idx += 256) Vp[blk + idx] = V[(idx >> 6) * P65 + (idx & 63)];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++) {
+        doublex4 acc[4];
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[tj][e] = 0.0;
+#pragma unroll 4
+        for (int ks = 0; ks < SB_G / 4; ks++) {
+            const double a = V[(32 * wave + 16 * rt + r16) * P65 + 4 * ks + k4];
+#pragma unroll
+            for (int tj = 0; tj < 4; tj++) acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Tm[(4 * ks + k4) * P65 + 16 * tj + r16], acc[tj], 0, 0, 0);
         }
-        __syncthreads();
-        if (tid < j) Tm[tid * P65 + j] = v;
-        if (tid == j) Tm[j * P65 + j] = tj;
-        __syncthreads();
-    }
-    // V and V T out (row-major 128 x 64)
-    for (int idx = tid; idx < VR * SB_G; idx += 256) {
-        const int r = idx >> 6, j = idx & 63;
-        double s = 0.0;
-        for (int l = 0; l <= j; l++) s = fma(V[r * P65 + l], Tm[l * P65 + j], s);
-        Vp[blk + idx] = V[r * P65 + j];
-        Vtp[blk + idx] = s;
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) Vtp[blk + (size_t)(32 * wave + 16 * rt + k4 + 4 * e) * SB_G + 16 * tj + r16] = acc[tj][e];
     }
 }
 
