@@ -963,8 +963,10 @@ __device__ __forceinline__ void bc_give_up(int *ctl, int *fail, int s, int K)
     if ((++(spins_) & 63) == 0 &&                                                                                                 \
         ((spins_) > (1 << 20) || __hip_atomic_load(&(ctl_)[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { (bad_) = true; break; }
 
-__global__ __launch_bounds__(64 * NW) void bc_stationary_kernel(int n, double *S, double *VV, double *TAU, int nk, double *mail, int nwg, int *ctl, int *fail)
+template <int NWT>      // wavefronts per workgroup: 16 (one workgroup per CU) or 8 (two per CU: matrices of up to 2 x 64 x CUs rows)
+__global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *S, double *VV, double *TAU, int nk, double *mail, int nwg, int *ctl, int *fail)
 {
+    constexpr int NW = NWT, RW = B / NWT;
     extern __shared__ double bc_lds[];
     double *Wn = bc_lds;
     double *vcur = Wn + B * WP, *vprev = vcur + B, *wv = vprev + B, *qv = wv + B;
@@ -1147,21 +1149,27 @@ int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2W
     PG_HIP(hipMemsetAsync(w.VV, 0, (size_t)n * n * 8, st));
     PG_HIP(hipMemsetAsync(w.TAU, 0, (size_t)n * w.nk * 8, st));
     if (n >= 3) {
-        constexpr int BC_LDS = BC_LDS_BYTES;
+        constexpr int BC_LDS = BC_LDS_BYTES, BC_LDS8 = (B * WP + 4 * B + 2 * 8 * B + 4) * 8;
         static bool attr_done = false;
         if (!attr_done) {
             PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS));
-            PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_stationary_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS));
+            PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_stationary_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS));
+            PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_stationary_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS8));
             attr_done = true;
         }
-        // one workgroup per block of 64 rows, all of them resident at once (they wait for each other): only while the chip has a CU
-        // for each; larger matrices take the kernel that carries the rows through memory
+        // one workgroup per block of 64 rows, all of them resident at once (they wait for each other): one per CU with 16 wavefronts,
+        // two per CU with 8 (76 KB of LDS each; a step's busy time 5.2 instead of 4.9 us); larger matrices take the kernel that carries
+        // the rows through memory.  Should the grid not become resident after all, the bounded waits raise the flag and the caller
+        // falls back.
         const int nblk = (n - 1 + B - 1) / B;
-        bool stationary = nblk <= std::min(ctx->num_cu, w.kmax);
+        int per_cu = (nblk <= ctx->num_cu) ? 1 : 2;
+        if (const char *e_ = getenv("PG_BC_PER_CU")) per_cu = std::max(1, std::min(atoi(e_), 2));      // A/B and tests
+        bool stationary = nblk <= std::min(per_cu * ctx->num_cu, w.kmax);
         if (const char *e_ = getenv("PG_BC_STATIONARY")) stationary = stationary && atoi(e_) != 0;
         if (stationary) {
             PG_HIP(hipMemsetAsync(w.mail, 0, (size_t)nblk * MB_LD * 8, st));
-            bc_stationary_kernel<<<nblk, 64 * NW, BC_LDS, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.mail, nblk, w.prog + n, w.fail);
+            if (per_cu == 1) bc_stationary_kernel<NW><<<nblk, 64 * NW, BC_LDS, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.mail, nblk, w.prog + n, w.fail);
+            else bc_stationary_kernel<8><<<nblk, 64 * 8, BC_LDS8, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.mail, nblk, w.prog + n, w.fail);
         } else {
             // a sweep trails the one ahead by two blocks: n / 128 sweeps are in flight at most; workgroups beyond that would only poll
             int nwg = n / (2 * B) + 4;

@@ -461,10 +461,14 @@ __global__ void gather_z_kernel(int n, const double *Q, const int *zrow, double 
 
 struct Rot { int a, b; double c, s; };
 
+// One merge of a level, as the batched kernels below see it (the lower levels of the tree hold hundreds of small merges: eight
+// launches each made those levels launch-bound — 156 merges of 64 rows: 6.9 ms at n = 10 000)
+struct MergeDesc { int s, n1, nm, k, k1, k2, rot_off, nrot; double rho; };
+
 // apply the deflation rotations (in order) to columns of Q, rows [r0, r0+nrow): one thread per row
-__global__ void givens_kernel(int n, int r0, int nrow, double *Q, const Rot *rots, int nrot)
+__device__ __forceinline__ void givens_body(int n, int r0, int nrow, double *Q, const Rot *rots, int nrot, int bx)
 {
-    int r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+    int r = r0 + bx * blockDim.x + threadIdx.x;
     if (r >= r0 + nrow) return;
     double *row = Q + (size_t)r * n;
     for (int t = 0; t < nrot; t++) {
@@ -474,16 +478,32 @@ __global__ void givens_kernel(int n, int r0, int nrow, double *Q, const Rot *rot
         row[g.b] = g.c * y - g.s * x;
     }
 }
+__global__ void givens_kernel(int n, int r0, int nrow, double *Q, const Rot *rots, int nrot) { givens_body(n, r0, nrow, Q, rots, nrot, blockIdx.x); }
+__global__ void givens_batched_kernel(int n, const MergeDesc *md, double *Q, const Rot *rots)
+{
+    const MergeDesc m = md[blockIdx.y];
+    if (m.nrot > 0) givens_body(n, m.s, m.nm, Q, rots + m.rot_off, m.nrot, blockIdx.x);
+}
 
 // Tp[r][jj] = Qin[r0+r][col[jj]] (jj < k: non-deflated, in secular order);  deflated columns go straight to Qout
-__global__ void permute_cols_kernel(int n, int r0, int nm, int k, const double *Qin, const int *col, double *Tp, double *Qout)
+__device__ __forceinline__ void permute_cols_body(int n, int r0, int nm, int k, const double *Qin, const int *col, double *Tp, double *Qout, long long bx)
 {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long idx = bx * blockDim.x + threadIdx.x;
     if (idx >= (long long)nm * nm) return;
     int r = (int)(idx / nm), jj = (int)(idx % nm);
     double v = Qin[(size_t)(r0 + r) * n + col[jj]];
     if (jj < k) Tp[(size_t)r * k + jj] = v;
     else Qout[(size_t)(r0 + r) * n + r0 + jj] = v;
+}
+__global__ void permute_cols_kernel(int n, int r0, int nm, int k, const double *Qin, const int *col, double *Tp, double *Qout)
+{
+    permute_cols_body(n, r0, nm, k, Qin, col, Tp, Qout, blockIdx.x);
+}
+// batched: the work space of the merge that starts at row s is the slice s n .. of Tp / Um (nm k <= nm n doubles), s .. of zh
+__global__ void permute_cols_batched_kernel(int n, const MergeDesc *md, const double *Qin, const int *col, double *Tp, double *Qout)
+{
+    const MergeDesc m = md[blockIdx.y];
+    permute_cols_body(n, m.s, m.nm, m.k, Qin, col + m.s, Tp + (size_t)m.s * n, Qout, blockIdx.x);
 }
 
 // One WAVEFRONT per root of  f(lam) = 1 + rho * sum_i w_i^2 / (dl_i - lam)  (rho > 0, dl strictly increasing);
@@ -496,10 +516,10 @@ __device__ __forceinline__ double wave_sum(double v)
     for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
     return v;
 }
-__global__ __launch_bounds__(256) void secular_kernel(int k, const double *dl, const double *w, double rho, const int *rp, double *Dm, double *lam_out)
+__device__ __forceinline__ void secular_body(int k, const double *dl, const double *w, double rho, const int *rp, double *Dm, double *lam_out, int bx)
 {
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = bx * 4 + (threadIdx.x >> 6);
     if (j >= k) return;
     const double eps = 1.1102230246251565e-16;
     int org;
@@ -526,8 +546,8 @@ __global__ __launch_bounds__(256) void secular_kernel(int k, const double *dl, c
         double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0, sabs = 0.0;
         for (int i = lane; i < k; i += 64) {
             const double del = (dl[i] - dorg) - tau;
-            const double t = rho * w[i] * w[i] / del;
-            if (i <= jp) { psi += t; dpsi += t / del; } else { phi += t; dphi += t / del; }
+            const double rdel = 1.0 / del, t = rho * w[i] * w[i] * rdel, dt = t * rdel;      // one division per pole instead of two
+            if (i <= jp) { psi += t; dpsi += dt; } else { phi += t; dphi += dt; }
             sabs += fabs(t);
         }
         psi = wave_sum(psi); dpsi = wave_sum(dpsi); phi = wave_sum(phi); dphi = wave_sum(dphi); sabs = wave_sum(sabs);
@@ -568,12 +588,21 @@ __global__ __launch_bounds__(256) void secular_kernel(int k, const double *dl, c
     for (int i = lane; i < k; i += 64) Dm[(size_t)rp[i] * k + j] = (dl[i] - dorg) - tau;   // row of pole i: its slot in the type-grouped order
     if (lane == 0) lam_out[j] = dorg + tau;
 }
+__global__ __launch_bounds__(256) void secular_kernel(int k, const double *dl, const double *w, double rho, const int *rp, double *Dm, double *lam_out)
+{
+    secular_body(k, dl, w, rho, rp, Dm, lam_out, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void secular_batched_kernel(int n, const MergeDesc *md, const double *dl, const double *w, const int *rp, double *Dm, double *lam_out)
+{
+    const MergeDesc m = md[blockIdx.y];
+    secular_body(m.k, dl + m.s, w + m.s, m.rho, rp + m.s, Dm + (size_t)m.s * n, lam_out + m.s, blockIdx.x);
+}
 
 // zhat_i = sign(w_i) sqrt| Dm[i][i] * prod_{j != i} Dm[i][j] / (dl_i - dl_j) |   (one wavefront per i)
-__global__ __launch_bounds__(256) void zhat_kernel(int k, const double *dl, const double *w, const int *rp, const double *Dm, double *zh)
+__device__ __forceinline__ void zhat_body(int k, const double *dl, const double *w, const int *rp, const double *Dm, double *zh, int bx)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wave;
+    const int i = bx * 4 + wave;
     if (i >= k) return;
     const double *row = Dm + (size_t)rp[i] * k;
     const double di = dl[i];
@@ -582,36 +611,109 @@ __global__ __launch_bounds__(256) void zhat_kernel(int k, const double *dl, cons
     for (int s = 1; s < 64; s <<= 1) prod *= __shfl_xor(prod, s, 64);
     if (lane == 0) zh[i] = copysign(sqrt(fabs(prod)), w[i]);
 }
+__global__ __launch_bounds__(256) void zhat_kernel(int k, const double *dl, const double *w, const int *rp, const double *Dm, double *zh) { zhat_body(k, dl, w, rp, Dm, zh, blockIdx.x); }
+__global__ __launch_bounds__(256) void zhat_batched_kernel(int n, const MergeDesc *md, const double *dl, const double *w, const int *rp, const double *Dm, double *zh)
+{
+    const MergeDesc m = md[blockIdx.y];
+    zhat_body(m.k, dl + m.s, w + m.s, rp + m.s, Dm + (size_t)m.s * n, zh + m.s, blockIdx.x);
+}
 
 // U[:, j] = (zh_i / Dm[i][j])_i, normalised; in place over Dm.  64 columns per workgroup (coalesced across j), the rows
 // split over the 4 waves, column norms combined through LDS in a fixed order.
 // Two launches, rows cut into chunks of UV_ROWS so that a merge of k = 7 000 poles fills the chip (110 workgroups of the one-kernel
 // version left 60 % of the CUs idle, each thread walking 1 750 dependent load + divide steps twice: 18 ms per solve, now ~2):
-// (1) sums of squares of a chunk's rows per column -> part[chunk][j]; (2) the chunks' sums added in chunk order, rows scaled.
+// (1) the quotients in place and the sums of squares of a chunk's rows per column -> part[chunk][j]; (2) the chunks' sums added in
+// chunk order, rows scaled.
 constexpr int UV_ROWS = 256;
-__global__ __launch_bounds__(256) void uvec_norm_kernel(int k, const double *zh, const int *rp, const double *Dm, double *part)
+__device__ __forceinline__ void uvec_norm_body(int k, const double *zh, const int *rp, double *Dm, double *part, int bx, int by)
 {
     __shared__ double sh[4][64];
     const int jj = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + jj;
-    const int i0 = blockIdx.y * UV_ROWS, i1 = (i0 + UV_ROWS < k) ? i0 + UV_ROWS : k;
+    const int j = bx * 64 + jj;
+    const int i0 = by * UV_ROWS, i1 = (i0 + UV_ROWS < k) ? i0 + UV_ROWS : k;
+    if (i0 >= k || bx * 64 >= k) return;      // (batched launches are sized for the largest merge of the level; uniform per workgroup)
     double ss = 0.0;
     if (j < k)
-        for (int i = i0 + rg; i < i1; i += 4) { const double v = zh[i] / Dm[(size_t)rp[i] * k + j]; ss += v * v; }
+        for (int i = i0 + rg; i < i1; i += 4) { const size_t at = (size_t)rp[i] * k + j; const double v = zh[i] / Dm[at]; Dm[at] = v; ss += v * v; }
     sh[rg][jj] = ss;
     __syncthreads();
-    if (rg == 0 && j < k) part[(size_t)blockIdx.y * k + j] = ((sh[0][jj] + sh[1][jj]) + sh[2][jj]) + sh[3][jj];
+    if (rg == 0 && j < k) part[(size_t)by * k + j] = ((sh[0][jj] + sh[1][jj]) + sh[2][jj]) + sh[3][jj];
 }
-__global__ __launch_bounds__(256) void uvec_scale_kernel(int k, const double *zh, const int *rp, double *Dm, const double *part, int nchunk)
+__device__ __forceinline__ void uvec_scale_body(int k, const double *zh, const int *rp, double *Dm, const double *part, int nchunk, int bx, int by)
 {
     const int jj = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + jj;
+    const int j = bx * 64 + jj;
     if (j >= k) return;
     double ss = 0.0;
     for (int c = 0; c < nchunk; c++) ss += part[(size_t)c * k + j];
     const double inv = 1.0 / sqrt(ss);
-    const int i0 = blockIdx.y * UV_ROWS, i1 = (i0 + UV_ROWS < k) ? i0 + UV_ROWS : k;
-    for (int i = i0 + rg; i < i1; i += 4) { const size_t at = (size_t)rp[i] * k + j; const double v = zh[i] / Dm[at]; Dm[at] = v * inv; }
+    const int i0 = by * UV_ROWS, i1 = (i0 + UV_ROWS < k) ? i0 + UV_ROWS : k;
+    for (int i = i0 + rg; i < i1; i += 4) { const size_t at = (size_t)rp[i] * k + j; Dm[at] *= inv; }      // the quotients were left there by uvec_norm_kernel
+}
+__global__ __launch_bounds__(256) void uvec_norm_kernel(int k, const double *zh, const int *rp, double *Dm, double *part) { uvec_norm_body(k, zh, rp, Dm, part, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void uvec_scale_kernel(int k, const double *zh, const int *rp, double *Dm, const double *part, int nchunk)
+{
+    uvec_scale_body(k, zh, rp, Dm, part, nchunk, blockIdx.x, blockIdx.y);
+}
+// batched: the column norms' partial sums of the merge at row s live at part + s * pstride (pstride = n / UV_ROWS + 2 >= its chunks)
+__global__ __launch_bounds__(256) void uvec_norm_batched_kernel(int n, const MergeDesc *md, const double *zh, const int *rp, double *Dm, double *part, int pstride)
+{
+    const MergeDesc m = md[blockIdx.z];
+    uvec_norm_body(m.k, zh + m.s, rp + m.s, Dm + (size_t)m.s * n, part + (size_t)m.s * pstride, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void uvec_scale_batched_kernel(int n, const MergeDesc *md, const double *zh, const int *rp, double *Dm, const double *part, int pstride)
+{
+    const MergeDesc m = md[blockIdx.z];
+    uvec_scale_body(m.k, zh + m.s, rp + m.s, Dm + (size_t)m.s * n, part + (size_t)m.s * pstride, (m.k + UV_ROWS - 1) / UV_ROWS, blockIdx.x, blockIdx.y);
+}
+
+// Q_new = [Q1 0; 0 Q2] U for every merge of a level: blockIdx.y = 2 * merge + (0: upper rows x columns of types 1, 2 | 1: lower rows x
+// types 2, 3), blockIdx.x = 64 x 64 tile of that product; operands through LDS, fp64 MFMA (wavefront w: rows 16 w .. of the tile).
+// The sizes here are small (merges of up to 1024 rows): what matters is ONE launch per level instead of two per merge.
+__global__ __launch_bounds__(256) void merge_gemm_batched_kernel(int n, const MergeDesc *md, const double *Tp, const double *Um, double *Qout)
+{
+    constexpr int KC = 32, AP = KC + 1, TP = 65;            // 34 KB of static LDS (above 64 KB a static allocation is not honoured)
+    __shared__ double As[64 * AP], Bs[KC * TP];
+    const MergeDesc m = md[blockIdx.y >> 1];
+    const int part = blockIdx.y & 1, k = m.k;
+    if (k == 0) return;
+    const int n1 = m.n1, n2 = m.nm - m.n1, k12 = m.k1 + m.k2, k23 = k - m.k1;
+    const int M = part ? n2 : n1, K = part ? k23 : k12;
+    const int tn = (k + 63) / 64, tm = (M + 63) / 64;
+    if ((int)blockIdx.x >= tm * tn) return;
+    const int ti = blockIdx.x / tn, tj = blockIdx.x % tn;
+    const double *A = Tp + (size_t)m.s * n + (part ? (size_t)n1 * k + m.k1 : 0);       // M x K, ld k
+    const double *Bm = Um + (size_t)m.s * n + (part ? (size_t)m.k1 * k : 0);           // K x k, ld k
+    double *C = Qout + (size_t)(m.s + (part ? n1 : 0)) * n + m.s;                      // M x k, ld n
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+    doublex4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[t][e] = 0.0;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        for (int idx = tid; idx < 64 * KC; idx += 256) {
+            const int r = idx / KC, c = idx % KC;               // A tile: 64 rows x KC
+            As[r * AP + c] = (64 * ti + r < M && k0 + c < K) ? A[(size_t)(64 * ti + r) * k + k0 + c] : 0.0;
+            const int rb = idx >> 6, cb = idx & 63;             // B tile: KC rows x 64
+            Bs[rb * TP + cb] = (k0 + rb < K && 64 * tj + cb < k) ? Bm[(size_t)(k0 + rb) * k + 64 * tj + cb] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ks++) {
+            const double a = As[(16 * wave + r16) * AP + 4 * ks + k4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[(4 * ks + k4) * TP + 16 * t + r16], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int row = 64 * ti + 16 * wave + k4 + 4 * e, col = 64 * tj + 16 * t + r16;
+            if (row < M && col < k) C[(size_t)row * n + col] = acc[t][e];
+        }
 }
 
 __global__ void copy_block_kernel(int n, int r0, int nm, const double *Qin, double *Qout)
@@ -700,6 +802,7 @@ struct StedcWork {
     double *Qa = nullptr, *Qb = nullptr, *Tp = nullptr, *Um = nullptr, *z = nullptr, *dnew = nullptr, *dl = nullptr, *w = nullptr, *zh = nullptr, *S = nullptr, *unorm = nullptr;
     int *ibuf = nullptr;   // zrow | col | leaf tables
     Rot *rots = nullptr;
+    MergeDesc *mdesc = nullptr;   // the merges of one level (batched kernels)
 };
 
 // T = tridiag(d, e) (host arrays, length n / n-1) -> ascending eigenvalues (host) and Z (device, n x n row-major,
@@ -808,7 +911,37 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
         PG_HIP(hipMemcpyAsync(wk.w, dlw.data() + n, (size_t)n * 8, hipMemcpyHostToDevice, st));
         mark("  plan+copy", nb, 0);
         size_t roff = 0;
+        int nm_max = 0, k_max = 0;
+        for (auto &mp : plans) { nm_max = std::max(nm_max, mp.nm); k_max = std::max(k_max, mp.k); }
+        const int batch_max = getenv("PG_DC_BATCH_MAX") ? atoi(getenv("PG_DC_BATCH_MAX")) : 1024;      // 0: every merge on its own (A/B, tests)
+        const bool batched = plans.size() >= 2 && nm_max <= batch_max;
+        if (batched) {
+            // the small merges of a low level: one launch per kernel for all of them (work space slices by the merge's first row)
+            std::vector<MergeDesc> md(plans.size());
+            for (size_t q = 0; q < plans.size(); q++) {
+                const MergePlan &mp = plans[q];
+                md[q] = MergeDesc{mp.s, mp.n1, mp.nm, mp.k, mp.k1, mp.k2, (int)roff, (int)mp.rots.size(), mp.rho};
+                roff += mp.rots.size();
+            }
+            PG_HIP(hipMemcpyAsync(wk.mdesc, md.data(), md.size() * sizeof(MergeDesc), hipMemcpyHostToDevice, st));
+            const unsigned nmrg = (unsigned)plans.size();
+            const int pstride = n / UV_ROWS + 2;
+            if (rot_total > 0) givens_batched_kernel<<<dim3((nm_max + 255) / 256, nmrg), 256, 0, st>>>(n, wk.mdesc, Qin, wk.rots);
+            permute_cols_batched_kernel<<<dim3((unsigned)(((size_t)nm_max * nm_max + 255) / 256), nmrg), 256, 0, st>>>(n, wk.mdesc, Qin, wk.ibuf + n, wk.Tp, Qout);
+            if (k_max > 0) {
+                const int *rp = wk.ibuf + 2 * n;
+                const unsigned nchunk = (unsigned)((k_max + UV_ROWS - 1) / UV_ROWS), ktile = (unsigned)((k_max + 63) / 64);
+                secular_batched_kernel<<<dim3((k_max + 3) / 4, nmrg), 256, 0, st>>>(n, wk.mdesc, wk.dl, wk.w, rp, wk.Um, wk.dnew);
+                zhat_batched_kernel<<<dim3((k_max + 3) / 4, nmrg), 256, 0, st>>>(n, wk.mdesc, wk.dl, wk.w, rp, wk.Um, wk.zh);
+                uvec_norm_batched_kernel<<<dim3(ktile, nchunk, nmrg), 256, 0, st>>>(n, wk.mdesc, wk.zh, rp, wk.Um, wk.unorm, pstride);
+                uvec_scale_batched_kernel<<<dim3(ktile, nchunk, nmrg), 256, 0, st>>>(n, wk.mdesc, wk.zh, rp, wk.Um, wk.unorm, pstride);
+                const unsigned tiles = (unsigned)(((nm_max + 63) / 64) * ktile);
+                merge_gemm_batched_kernel<<<dim3(tiles, 2 * nmrg), 256, 0, st>>>(n, wk.mdesc, wk.Tp, wk.Um, Qout);
+            }
+            PG_HIP(hipGetLastError());
+        }
         for (auto &mp : plans) {
+            if (batched) break;
             const int nm = mp.nm, k = mp.k, s = mp.s;
             if (!mp.rots.empty()) {
                 givens_kernel<<<(nm + 255) / 256, 256, 0, st>>>(n, s, nm, Qin, wk.rots + roff, (int)mp.rots.size());
@@ -879,6 +1012,7 @@ static int stedc_alloc(int n, StedcWork &wk)
     for (int k = 0; k < 11 && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
     if (!rc && hipMalloc(&wk.ibuf, (3 * (size_t)n + 16) * 4) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
     if (!rc && hipMalloc(&wk.rots, ((size_t)n + 1) * sizeof(Rot)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
+    if (!rc && hipMalloc(&wk.mdesc, ((size_t)n / DC_LEAF + 2) * sizeof(MergeDesc)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
     return rc;
 }
 static void stedc_free(StedcWork &wk)
@@ -886,6 +1020,7 @@ static void stedc_free(StedcWork &wk)
     for (double *p : {wk.Qa, wk.Qb, wk.Tp, wk.Um, wk.z, wk.dnew, wk.dl, wk.w, wk.zh, wk.S, wk.unorm}) if (p) (void)hipFree(p);
     if (wk.ibuf) (void)hipFree(wk.ibuf);
     if (wk.rots) (void)hipFree(wk.rots);
+    if (wk.mdesc) (void)hipFree(wk.mdesc);
     wk = StedcWork{};
 }
 

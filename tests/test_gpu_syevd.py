@@ -87,9 +87,13 @@ def _tridiags():
     return out
 
 
+@pytest.mark.parametrize("batch", ["default", "0"])
 @pytest.mark.parametrize("name", list(_tridiags().keys()))
-def test_stedc_divide_and_conquer(name, ctx):
-    """T = Z diag(lam) Z' for hard tridiagonals: eigenvalues vs LAPACK (fp64), residual and orthogonality."""
+def test_stedc_divide_and_conquer(name, batch, ctx, monkeypatch):
+    """T = Z diag(lam) Z' for hard tridiagonals: eigenvalues vs LAPACK (fp64), residual and orthogonality — with the small merges of a
+    level in batched launches (default) and every merge on its own (PG_DC_BATCH_MAX=0)."""
+    if batch != "default":
+        monkeypatch.setenv("PG_DC_BATCH_MAX", batch)
     import scipy.linalg as sl
     from pygemma_amd import _lib
     L = _lib.load()
@@ -190,11 +194,12 @@ def test_syevd_structured_matrices(name, n, stages, ctx, monkeypatch):
     assert (ev32 >= 0).all() and np.isfinite(U32).all()
 
 
-@pytest.mark.parametrize("stationary", [1, 0])
+@pytest.mark.parametrize("stationary", [1, 2, 0])
 @pytest.mark.parametrize("n", [192, 300, 777, 1300])
 def test_two_stage_pieces(n, stationary, ctx, monkeypatch):
     """The two stages of the tridiagonalisation one at a time (csrc/sb2.hip), against fp64 LAPACK, with both bulge-chasing kernels
-    (band rows stationary in LDS — the default up to one row block per CU — and rows carried through memory):
+    (band rows stationary in LDS, 16 wavefronts per workgroup — the default up to one row block per CU — or 8, two workgroups per CU; rows
+    carried through memory):
     stage 1: the band matrix keeps K's spectrum, Q1 (the back-transformation applied to I) is orthogonal and Q1 B Q1' = K, no panel
              needed the fallback on a full-rank K;
     stage 2: the tridiagonal keeps the band's spectrum, Q2 orthogonal, Q2 T Q2' = B, no wait of the bulge-chasing kernel expired."""
@@ -217,7 +222,8 @@ def test_two_stage_pieces(n, stationary, ctx, monkeypatch):
     assert np.abs(Q1 @ Bm @ Q1.T - K64).max() <= 1e-12 * nrm
     dB, dd, de = ctx.to_device(Bm), ctx.alloc(n * 8), ctx.alloc(n * 8)
     dZ.upload(np.eye(n))
-    monkeypatch.setenv("PG_BC_STATIONARY", str(stationary))
+    monkeypatch.setenv("PG_BC_STATIONARY", "1" if stationary else "0")
+    monkeypatch.setenv("PG_BC_PER_CU", str(max(stationary, 1)))       # 2: the 8-wavefront kernel that runs two workgroups per CU
     _lib.check(L.pgx_sb2_stage2_dev(ctx.handle, n, dB.ptr, dd.ptr, de.ptr, dZ.ptr, flags), "stage 2")
     assert list(flags)[:2] == [0, 0]
     d, e, Q2 = dd.download((n,), np.float64), de.download((n,), np.float64)[: n - 1], dZ.download((n, n), np.float64)
