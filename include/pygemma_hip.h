@@ -231,7 +231,7 @@ int pg_kinship_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *G, int64
  * Reads the LOWER triangle of row-major K (n x n, float32, device).  Computes in fp64; delivers ascending
  * eigenvalues clamped at 0 (lmm/lmm.py:157) as float32, and U (column j = eigenvector j) as float32
  * (and optionally fp64 for the invariant checks: U64/evals64 may be NULL).
- * Two reductions to tridiagonal form behind this one entry point: from n = 1536 on, dense -> band (fp64 MFMA GEMMs) -> tridiagonal
+ * Two reductions to tridiagonal form behind this one entry point: from n = 768 on, dense -> band (fp64 MFMA GEMMs) -> tridiagonal
  * (persistent bulge-chasing kernel) with two blocked back-transformations (csrc/sb2.hip); below that, and for a K whose panels the
  * band reduction cannot factor (rank-deficient K: decided on the device), the one-stage Householder reduction (csrc/syevd.hip).
  * Environment, for tests and A/B timing only: PG_SYEVD_STAGES=1|2 forces a path, PG_SYEVD_TIMING=1 prints phase times.

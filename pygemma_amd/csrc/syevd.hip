@@ -1273,12 +1273,8 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
     StedcWork wk;
     double *A = nullptr, *dd = nullptr, *de = nullptr, *dev_ev = nullptr;
     int rc = PG_OK;
-    hipStream_t side_c = nullptr;       // set once the side stream exists (see below)
-    hipEvent_t ev_c = nullptr;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(st);
-        if (side_c) { (void)hipStreamSynchronize(side_c); (void)hipStreamDestroy(side_c); side_c = nullptr; }
-        if (ev_c) { (void)hipEventDestroy(ev_c); ev_c = nullptr; }
         for (double *p : {A, dd, de, dev_ev}) if (p) (void)hipFree(p);
         sb2_free(sw);
         stedc_free(wk);
@@ -1309,20 +1305,14 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
         cleanup();
         return PG_RETRY_ONESTAGE;
     }
-    // the reflector blocks of the second back-transformation need only the reflectors: built on a second stream beside the divide &
-    // conquer, whose many small, host-paced launches leave the chip mostly idle (11 ms at n = 10 000)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_prep = nullptr;
+    // the reflector blocks of the second back-transformation need only the reflectors: enqueued here, they are built while the divide
+    // & conquer's host part solves the leaves (2.4 ms at n = 10 000 with the chip idle; the blocks take 2.2).  (A second stream beside the
+    // divide & conquer did the same for a slower version of that kernel; creating and destroying it cost ~2 ms per solve.)
     bool prepared = false;
-    if (!rc && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev_prep, hipEventDisableTiming) == hipSuccess) {
-        // (the stream has just been synchronised: the reflectors are complete)
-        if (bt2_prep_device(ctx, n, sw, side) == PG_OK && hipEventRecord(ev_prep, side) == hipSuccess) prepared = true;
-    }
-    side_c = side; ev_c = ev_prep;
+    if (!rc) { rc = bt2_prep_device(ctx, n, sw, st); prepared = (rc == PG_OK); }
     double *Z = nullptr;
     if (!rc) rc = stedc_device(ctx, n, hd.data(), he.data(), ev, wk, &Z);
     mark("divide&conquer");
-    if (prepared && hipStreamWaitEvent(st, ev_prep, 0) != hipSuccess) { (void)hipStreamSynchronize(side); }
     if (!rc) rc = bt2_device(ctx, n, Z, sw, prepared);
     mark("back-transform 2");
     if (!rc) rc = bt1_device(ctx, n, Z, sw);
@@ -1344,8 +1334,8 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
 }
 
 #ifndef PG_SYEVD2_MIN_N
-#define PG_SYEVD2_MIN_N 1536     // profiles/r03_other_sizes.txt, second call: the two-stage path is ahead from n ~ 600 on (768: 18 vs 20 ms; 1 940: 38 vs 52;
-                                 // 10 000: 330 vs 588); a process's first solve pays ~10 ms more for it (more kernels to load), even at n ~ 1 500
+#define PG_SYEVD2_MIN_N 768      // profiles/r03_other_sizes.txt: the two-stage path is ahead from here on, first call of a process included
+                                 // (768: 15 vs 20 ms, first call 17 vs 24; 1 940: 32 vs 51; 10 000: 299 vs 561)
 #endif
 #ifndef PG_SYEVD2_MAX_N
 #define PG_SYEVD2_MAX_N 24000    // work space of the two-stage path ~ 12 n^2 doubles
