@@ -9,14 +9,17 @@
 //            depth 2b with operands [V W] and [W V] (the second read from the first with its k index XOR-ed by 64).
 //            A panel that CholeskyQR2 cannot factor to working accuracy (rank-deficient K) raises a device flag; the caller then
 //            solves with the one-stage path.
-//   stage 2  band -> tridiagonal by bulge chasing in ONE persistent kernel: workgroups take sweeps from a queue in order; a step
-//            (sweep s, block k) owns the 64 rows r0 = s + 1 + 64 k .. of the compact band and (1) applies the previous step's
-//            reflector from the right, (2) forms its own reflector from the first column, (3) applies it from the left and
-//            (4) on both sides of the diagonal block — all in LDS; step (s + 1, k) waits for (s, k + 1) through a per-sweep
-//            progress word (write-through stores, drained, then the flag: the hand-off of the MI355X guide's Guideline 16).
+//   stage 2  band -> tridiagonal by bulge chasing in ONE persistent kernel.  A step (sweep s, block K) owns the 64 rows
+//            r0 = s + 1 + 64 K .. of the compact band and (1) applies the previous step's reflector from the right, (2) forms its own
+//            reflector from the first column, (3) applies it from the left and (4) on both sides of the diagonal block — all in LDS.
+//            bc_stationary_kernel: workgroup K does step (s, K) of every sweep and KEEPS its rows in LDS; a row and a reflector per
+//            sweep travel between neighbours through mailboxes of self-validating 16-byte chunks.  bc_kernel (matrices with more
+//            row blocks than resident workgroups): rows through memory, a progress word per sweep (write-through stores, drained,
+//            then the flag: the hand-off of the MI355X guide's Guideline 16).
 //   back     U = Q1 (Q2 Z).  Q2: the length-64 reflectors of 64 consecutive sweeps at one block index form a 127 x 64 parallelogram
-//            with a compact-WY factor; blocks on an anti-diagonal (group, block index) wavefront touch disjoint rows 128 apart,
-//            so each wavefront is two batched GEMMs.  Q1: blocks of 256 reflectors as in the one-stage solver.
+//            with a compact-WY factor; 2 x 2 super-blocks (two groups x two block indices, 255 rows) on anti-diagonal wavefronts touch
+//            disjoint rows 256 apart; a workgroup applies the four blocks to a 256 x 64 slab of Z held in registers.  Q1: blocks of
+//            256 reflectors as in the one-stage solver.
 #include "sb2.hpp"
 #include "dgemm.hpp"
 
