@@ -235,7 +235,8 @@ int pg_kinship_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *G, int64
  * (persistent bulge-chasing kernel) with two blocked back-transformations (csrc/sb2.hip); below that, and for a K whose panels the
  * band reduction cannot factor (rank-deficient K: decided on the device), the one-stage Householder reduction (csrc/syevd.hip).
  * Environment, for tests and A/B timing only: PG_SYEVD_STAGES=1|2 forces a path, PG_SYEVD_TIMING=1 prints phase times.
- * Work space ~ 12 n^2 doubles on the two-stage path (n <= 24 000), ~ 8 n^2 on the one-stage path. */
+ * Work space ~ 10 n^2 doubles on the two-stage path (200 GB at n = 50 000; when the device cannot give it the one-stage path is taken),
+ * ~ 8 n^2 on the one-stage path. */
 int pg_syevd_dev(pg_ctx *ctx, int64_t n, const float *K, float *evals, float *U, double *evals64, double *U64);
 
 /* ---- Inspection surface: the model-level functions the reference's tests call directly

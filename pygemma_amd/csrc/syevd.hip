@@ -803,6 +803,7 @@ struct StedcWork {
     int *ibuf = nullptr;   // zrow | col | leaf tables
     Rot *rots = nullptr;
     MergeDesc *mdesc = nullptr;   // the merges of one level (batched kernels)
+    bool borrowed = false;        // Qa, Tp, Um belong to the caller (set before stedc_alloc): buffers of the two-stage path that are idle by then
 };
 
 // T = tridiag(d, e) (host arrays, length n / n-1) -> ascending eigenvalues (host) and Z (device, n x n row-major,
@@ -1009,7 +1010,8 @@ static int stedc_alloc(int n, StedcWork &wk)
     double **bufs[] = {&wk.Qa, &wk.Qb, &wk.Tp, &wk.Um, &wk.z, &wk.dnew, &wk.dl, &wk.w, &wk.zh, &wk.S, &wk.unorm};
     size_t sizes[] = {(size_t)n * n, (size_t)n * n, (size_t)n * n, (size_t)n * n, (size_t)n, (size_t)n, (size_t)n, (size_t)n, (size_t)n, (size_t)n * (DC_LEAF + 1),
                       ((size_t)n / UV_ROWS + 2) * n};
-    for (int k = 0; k < 11 && !rc; k++) rc = alloc_d(bufs[k], sizes[k]);
+    for (int k = 0; k < 11 && !rc; k++)
+        if (!*bufs[k]) rc = alloc_d(bufs[k], sizes[k]);          // (borrowed buffers are already set)
     if (!rc && hipMalloc(&wk.ibuf, (3 * (size_t)n + 16) * 4) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
     if (!rc && hipMalloc(&wk.rots, ((size_t)n + 1) * sizeof(Rot)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
     if (!rc && hipMalloc(&wk.mdesc, ((size_t)n / DC_LEAF + 2) * sizeof(MergeDesc)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
@@ -1017,6 +1019,7 @@ static int stedc_alloc(int n, StedcWork &wk)
 }
 static void stedc_free(StedcWork &wk)
 {
+    if (wk.borrowed) wk.Qa = wk.Tp = wk.Um = nullptr;
     for (double *p : {wk.Qa, wk.Qb, wk.Tp, wk.Um, wk.z, wk.dnew, wk.dl, wk.w, wk.zh, wk.S, wk.unorm}) if (p) (void)hipFree(p);
     if (wk.ibuf) (void)hipFree(wk.ibuf);
     if (wk.rots) (void)hipFree(wk.rots);
@@ -1284,8 +1287,20 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
     if (!rc) rc = alloc_d(&de, (size_t)n);
     if (!rc) rc = alloc_d(&dev_ev, (size_t)n);
     if (!rc) rc = sb2_alloc(n, sw);
-    if (!rc) rc = stedc_alloc(n, wk);
-    if (rc) { cleanup(); return rc; }
+    if (!rc) {
+        // three of the divide & conquer's four n x n buffers are buffers of the reduction that are idle by then: A (done with once the
+        // band is extracted), the reflectors of stage 2 (done with once their blocks are built) and the transposed-panel space of stage 1
+        // — 10 n^2 doubles in all instead of 13 (hipMalloc of tens of GB is not free: 2.6 s for 94 GB at n = 30 000)
+        wk.borrowed = true;
+        wk.Tp = A; wk.Um = sw.VV; wk.Qa = sw.Wws;
+        rc = stedc_alloc(n, wk);
+    }
+    if (rc) {
+        cleanup();
+        // not enough device memory for this path's 10 n^2 doubles: the one-stage path needs about half
+        if (rc == PG_ENOMEM) { (void)hipGetLastError(); return PG_RETRY_ONESTAGE; }
+        return rc;
+    }
     mark("allocate");
     sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n, n, K, A);
     rc = sy2sb_device(ctx, n, A, sw);
@@ -1338,7 +1353,7 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
                                  // (768: 15 vs 20 ms, first call 17 vs 24; 1 940: 32 vs 51; 10 000: 299 vs 561)
 #endif
 #ifndef PG_SYEVD2_MAX_N
-#define PG_SYEVD2_MAX_N 24000    // work space of the two-stage path ~ 12 n^2 doubles
+#define PG_SYEVD2_MAX_N 65535    // no limit of its own: work space 10 n^2 doubles (200 GB at n = 50 000); when the device cannot give that, the one-stage path is taken
 #endif
 extern "C" int pg_syevd_dev(pg_ctx *ctx, int64_t n64, const float *K, float *evals, float *U, double *evals64, double *U64)
 {

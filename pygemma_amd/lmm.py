@@ -188,7 +188,7 @@ class _Prefetch:
             ctx = _lib.Context(g)
             self.ctxs.append(ctx)
             free, _total = ctx.mem_info()
-            reserve = (72 * n * n if g == 0 else 12 * n * n) + 2 * _BATCH_BYTES + _PREFETCH_MARGIN
+            reserve = (96 * n * n if g == 0 else 12 * n * n) + 2 * _BATCH_BYTES + _PREFETCH_MARGIN      # GPU 0: the eigensolver's 10 n^2 doubles + its outputs
             budget = min(free - reserve, _PREFETCH_MAX)
             pb_max, ldX = _batch_geometry(n, a, b)
             per = n * ldX * esz
