@@ -235,6 +235,35 @@ def test_two_stage_pieces(n, stationary, ctx, monkeypatch):
         b.free()
 
 
+@pytest.mark.parametrize("n", [300, 1000])
+def test_stage2_back_transformation_one_block_per_trip(n, ctx, monkeypatch):
+    """PG_BT2_FOUR=0: the stage-2 reflector blocks applied one per trip of a slab (bt2_apply_kernel) instead of four (bt2_apply4_kernel):
+    same Q2 to rounding — both orthogonal, both reproduce the band matrix."""
+    import scipy.linalg as sl
+    from pygemma_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)); A = A + A.T
+    i, j = np.indices((n, n)); Bm = np.where(np.abs(i - j) <= 64, A, 0.0)
+    nrm = np.abs(Bm).max()
+    flags = (C.c_int * 4)()
+    dB, dd, de, dZ = ctx.to_device(Bm), ctx.alloc(n * 8), ctx.alloc(n * 8), ctx.to_device(np.eye(n))
+    out = {}
+    for four in ("1", "0"):
+        monkeypatch.setenv("PG_BT2_FOUR", four)
+        dZ.upload(np.eye(n))
+        _lib.check(L.pgx_sb2_stage2_dev(ctx.handle, n, dB.ptr, dd.ptr, de.ptr, dZ.ptr, flags), "stage 2")
+        assert list(flags)[:2] == [0, 0]
+        d, e, Q2 = dd.download((n,), np.float64), de.download((n,), np.float64)[: n - 1], dZ.download((n, n), np.float64)
+        T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+        assert np.abs(Q2.T @ Q2 - np.eye(n)).max() <= 1e-13
+        assert np.abs(Q2 @ T @ Q2.T - Bm).max() <= 1e-12 * nrm
+        out[four] = Q2
+    assert np.abs(out["1"] - out["0"]).max() <= 1e-13
+    for b in (dB, dd, de, dZ):
+        b.free()
+
+
 def test_two_stage_flags_a_rank_deficient_panel(ctx):
     """A K whose first panel has dependent columns: stage 1 must raise its flag (pg_syevd_dev then takes the one-stage path)."""
     from pygemma_amd import _lib
