@@ -501,12 +501,25 @@ size_t sb2_bytes(int n)
                 (ng + 1) * B * B + 2 * (size_t)BT1_BLOCK * BT1_BLOCK + 2 * (size_t)BT1_BLOCK * n + 64 * B * B + (kmax + 1) * SB_MAIL_LD) + 4 * ((size_t)n + 64);
 }
 
-static int alloc_d2(double **p, size_t count)
+thread_local DevArena *g_arena = nullptr;
+int dev_alloc(void **p, size_t bytes)
 {
-    hipError_t e = hipMalloc(p, (count ? count : 1) * sizeof(double));
-    if (e != hipSuccess) { set_error("hipMalloc(%zu doubles) failed: %s", count, hipGetErrorString(e)); *p = nullptr; return PG_ENOMEM; }
+    if (bytes == 0) bytes = 8;
+    if (g_arena && g_arena->base) {
+        const size_t at = (g_arena->off + 255) & ~(size_t)255;
+        if (at + bytes <= g_arena->cap) { *p = g_arena->base + at; g_arena->off = at + bytes; return PG_OK; }
+    }
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); *p = nullptr; return PG_ENOMEM; }
     return PG_OK;
 }
+void dev_free(void *p)
+{
+    if (!p) return;
+    if (g_arena && g_arena->base && (char *)p >= g_arena->base && (char *)p < g_arena->base + g_arena->cap) return;
+    (void)hipFree(p);
+}
+static int alloc_d2(double **p, size_t count) { return dev_alloc(reinterpret_cast<void **>(p), count * sizeof(double)); }
 
 int sb2_alloc(int n, Sb2Work &w)
 {
@@ -525,17 +538,17 @@ int sb2_alloc(int n, Sb2Work &w)
         {&w.Vtp, (size_t)w.ng * w.kmax * 128 * SB_G}, {&w.Wws, ((size_t)w.kmax + 1) * SB_G * n}, {&w.G, (size_t)BT1_BLOCK * BT1_BLOCK},
         {&w.T, (size_t)BT1_BLOCK * BT1_BLOCK}, {&w.W, (size_t)BT1_BLOCK * n}, {&w.W2, (size_t)BT1_BLOCK * n}, {&w.mail, ((size_t)w.kmax + 1) * SB_MAIL_LD}};
     for (auto &r : req) { if (!rc) rc = alloc_d2(r.p, r.cnt); }
-    if (!rc && hipMalloc(&w.prog, ((size_t)n + 16) * sizeof(int)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
-    if (!rc && hipMalloc(&w.fail, 4 * sizeof(int)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
+    if (!rc) rc = dev_alloc(reinterpret_cast<void **>(&w.prog), ((size_t)n + 16) * sizeof(int));
+    if (!rc) rc = dev_alloc(reinterpret_cast<void **>(&w.fail), 4 * sizeof(int));
     if (rc) sb2_free(w);
     return rc;
 }
 
 void sb2_free(Sb2Work &w)
 {
-    for (double *p : {w.Vst, w.Tst, w.VW, w.Qb, w.sm, w.S, w.VV, w.TAU, w.Vp, w.Vtp, w.Wws, w.G, w.T, w.W, w.W2, w.mail}) if (p) (void)hipFree(p);
-    if (w.prog) (void)hipFree(w.prog);
-    if (w.fail) (void)hipFree(w.fail);
+    for (double *p : {w.Vst, w.Tst, w.VW, w.Qb, w.sm, w.S, w.VV, w.TAU, w.Vp, w.Vtp, w.Wws, w.G, w.T, w.W, w.W2, w.mail}) dev_free(p);
+    dev_free(w.prog);
+    dev_free(w.fail);
     w = Sb2Work{};
 }
 

@@ -28,6 +28,14 @@ struct Sb2Work {
     int *fail = nullptr;      // 4 ints: [0] panel factorisation lost orthogonality / not positive definite, [1] bulge-chase wait expired
 };
 
+// One solve's work buffers out of ONE device allocation: ~30 hipMalloc / hipFree pairs cost 5 ms per solve (each hipFree waits for the
+// device).  While g_arena points at an arena, dev_alloc carves from it (256-byte aligned; falls back to hipMalloc when it is full) and
+// dev_free leaves pointers inside it alone; the owner frees the arena's base at the end.
+struct DevArena { char *base = nullptr; size_t off = 0, cap = 0; };
+extern thread_local DevArena *g_arena;
+int dev_alloc(void **p, size_t bytes);
+void dev_free(void *p);
+
 size_t sb2_bytes(int n);                 // device memory sb2_alloc takes (for the caller's budget)
 int sb2_alloc(int n, Sb2Work &w);
 void sb2_free(Sb2Work &w);

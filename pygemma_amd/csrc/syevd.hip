@@ -1012,27 +1012,22 @@ static int stedc_alloc(int n, StedcWork &wk)
                       ((size_t)n / UV_ROWS + 2) * n};
     for (int k = 0; k < 11 && !rc; k++)
         if (!*bufs[k]) rc = alloc_d(bufs[k], sizes[k]);          // (borrowed buffers are already set)
-    if (!rc && hipMalloc(&wk.ibuf, (3 * (size_t)n + 16) * 4) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
-    if (!rc && hipMalloc(&wk.rots, ((size_t)n + 1) * sizeof(Rot)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
-    if (!rc && hipMalloc(&wk.mdesc, ((size_t)n / DC_LEAF + 2) * sizeof(MergeDesc)) != hipSuccess) { set_error("hipMalloc failed"); rc = PG_ENOMEM; }
+    if (!rc) rc = dev_alloc(reinterpret_cast<void **>(&wk.ibuf), (3 * (size_t)n + 16) * 4);
+    if (!rc) rc = dev_alloc(reinterpret_cast<void **>(&wk.rots), ((size_t)n + 1) * sizeof(Rot));
+    if (!rc) rc = dev_alloc(reinterpret_cast<void **>(&wk.mdesc), ((size_t)n / DC_LEAF + 2) * sizeof(MergeDesc));
     return rc;
 }
 static void stedc_free(StedcWork &wk)
 {
     if (wk.borrowed) wk.Qa = wk.Tp = wk.Um = nullptr;
-    for (double *p : {wk.Qa, wk.Qb, wk.Tp, wk.Um, wk.z, wk.dnew, wk.dl, wk.w, wk.zh, wk.S, wk.unorm}) if (p) (void)hipFree(p);
-    if (wk.ibuf) (void)hipFree(wk.ibuf);
-    if (wk.rots) (void)hipFree(wk.rots);
-    if (wk.mdesc) (void)hipFree(wk.mdesc);
+    for (double *p : {wk.Qa, wk.Qb, wk.Tp, wk.Um, wk.z, wk.dnew, wk.dl, wk.w, wk.zh, wk.S, wk.unorm}) dev_free(p);
+    dev_free(wk.ibuf);
+    dev_free(wk.rots);
+    dev_free(wk.mdesc);
     wk = StedcWork{};
 }
 
-static int alloc_d(double **p, size_t count)
-{
-    hipError_t e = hipMalloc(p, (count ? count : 1) * sizeof(double));
-    if (e != hipSuccess) { set_error("hipMalloc(%zu doubles) failed: %s", count, hipGetErrorString(e)); *p = nullptr; return PG_ENOMEM; }
-    return PG_OK;
-}
+static int alloc_d(double **p, size_t count) { return dev_alloc(reinterpret_cast<void **>(p), count * sizeof(double)); }
 
 }  // namespace pg
 
@@ -1276,12 +1271,23 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
     StedcWork wk;
     double *A = nullptr, *dd = nullptr, *de = nullptr, *dev_ev = nullptr;
     int rc = PG_OK;
+    DevArena arena;
     auto cleanup = [&]() {
         (void)hipStreamSynchronize(st);
-        for (double *p : {A, dd, de, dev_ev}) if (p) (void)hipFree(p);
+        g_arena = &arena;
+        for (double *p : {A, dd, de, dev_ev}) dev_free(p);
         sb2_free(sw);
         stedc_free(wk);
+        g_arena = nullptr;
+        if (arena.base) (void)hipFree(arena.base);
+        arena = DevArena{};
     };
+    {   // everything below out of one allocation (when the device refuses it, the buffers are allocated one by one as before)
+        const size_t nn = (size_t)n * n;
+        arena.cap = sb2_bytes(n) + 8 * (2 * nn + (size_t)n * (DC_LEAF + 1) + ((size_t)n / UV_ROWS + 2) * n + 64 * (size_t)n) + ((size_t)1 << 20);
+        if (hipMalloc(reinterpret_cast<void **>(&arena.base), arena.cap) != hipSuccess) { (void)hipGetLastError(); arena = DevArena{}; }
+    }
+    g_arena = &arena;
     rc = alloc_d(&A, (size_t)n * n);
     if (!rc) rc = alloc_d(&dd, (size_t)n);
     if (!rc) rc = alloc_d(&de, (size_t)n);
@@ -1295,6 +1301,7 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
         wk.Tp = A; wk.Um = sw.VV; wk.Qa = sw.Wws;
         rc = stedc_alloc(n, wk);
     }
+    g_arena = nullptr;
     if (rc) {
         cleanup();
         // not enough device memory for this path's 10 n^2 doubles: the one-stage path needs about half
