@@ -46,6 +46,7 @@ __device__ __forceinline__ bool run_cond(const int *flag, int mode)
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int GBK = 64;   // samples per K-tile: the LDS image is 128-byte rows = 64 fp16
 
@@ -353,6 +354,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 #ifndef PG_GENO_GRP
 #define PG_GENO_GRP 4
 #endif
+template <int MF>      // MFMA shape: 16 = v_mfma_f32_16x16x32_f16 (shipped), 32 = v_mfma_f32_32x32x16_f16 (measured alternative: see launch_geno_gemm)
 __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 {
     if (!run_cond(gp.cond, gp.cmode)) return;      // uniform over the grid: every wave leaves before any barrier
@@ -372,13 +374,24 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
     const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves, each 64 (SNPs) x 128 (eigen indices)
     const int KT2 = 2 * gp.KT;
 
-    floatx4 acc[4][8];
+    // 128 accumulator registers either way: 4 x 8 tiles of 16 x 16 (4 floats per lane) or 2 x 4 tiles of 32 x 32 (16 per lane)
+    floatx4 acc[MF == 16 ? 4 : 1][MF == 16 ? 8 : 1];
+    floatx16 acc32[MF == 32 ? 2 : 1][MF == 32 ? 4 : 1];
+    if (MF == 16) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 8; j++)
+            for (int j = 0; j < 8; j++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) acc[i][j][e] = 0.0f;
+                for (int e = 0; e < 4; e++) acc[MF == 16 ? i : 0][MF == 16 ? j : 0][e] = 0.0f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc32[MF == 32 ? i : 0][MF == 32 ? j : 0][e] = 0.0f;
+    }
 
     // early wave w (0..3) fills rows 64w .. 64w+63 of the genotype tile, late wave w (4..7) rows 64(w-4) .. of the U-plane
     // tile: 8 instructions of 8 rows; rows past the end of the operand are clamped (their outputs are never stored)
@@ -434,20 +447,41 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
         else if (pl == 0) { if (ktile + 1 < gp.KT) { dmaA(ktile + 1, 1); issued = true; } }   // second half of K-tile T+1
         else { if (ktile + 2 < gp.KT) { dmaA(ktile + 2, 0); issued = true; } }              // first half of K-tile T+2
         halfx8 fb[8];
-        const int chunk0 = lane >> 4;
-        if (pl == 0) {
+        const int chunk0 = (MF == 16) ? (lane >> 4) : (lane >> 5);
+        if (MF == 16) {
+            if (pl == 0) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++)
+                for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int row = wm * 64 + i * 16 + (lane & 15);
-                    fa[ks][i] = *reinterpret_cast<const halfx8 *>(Acur + row * 128 + swz(row, 4 * ks + chunk0) * 16);
+                    for (int i = 0; i < 4; i++) {
+                        const int row = wm * 64 + i * 16 + (lane & 15);
+                        fa[ks][i] = *reinterpret_cast<const halfx8 *>(Acur + row * 128 + swz(row, 4 * ks + chunk0) * 16);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int row = wn * 128 + j * 16 + (lane & 15);
+                fb[j] = *reinterpret_cast<const halfx8 *>(Bcur + row * 128 + swz(row, chunk0) * 16);
+            }
+        } else {
+            // 32 x 32 x 16: lane l holds row l & 31 and the eight k of chunk 2 s + (l >> 5) of k-step s (four k-steps of 16 per K-tile);
+            // fa[s >> 1][2 (s & 1) + i] = genotype rows 32 i .. of k-step s;  fb[4 (s & 1) + j] = U rows 32 j .. of k-step s (s = 0, 1 here)
+            if (pl == 0) {
+#pragma unroll
+                for (int st = 0; st < 4; st++)
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int row = wm * 64 + i * 32 + (lane & 31);
+                        fa[st >> 1][2 * (st & 1) + i] = *reinterpret_cast<const halfx8 *>(Acur + row * 128 + swz(row, 2 * st + chunk0) * 16);
+                    }
+            }
+#pragma unroll
+            for (int st = 0; st < 2; st++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int row = wn * 128 + j * 32 + (lane & 31);
+                    fb[4 * st + j] = *reinterpret_cast<const halfx8 *>(Bcur + row * 128 + swz(row, 2 * st + chunk0) * 16);
                 }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int row = wn * 128 + j * 16 + (lane & 15);
-            fb[j] = *reinterpret_cast<const halfx8 *>(Bcur + row * 128 + swz(row, chunk0) * 16);
         }
         // everything this wave issued before this stage has landed
         if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -459,19 +493,47 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- MFMA phase
         __builtin_amdgcn_s_setprio(1);
-        // k-half 0 column by column; each U fragment is replaced by its k-half-1 successor as soon as its four MFMAs are
-        // issued (the read hides behind the remaining ones), then k-half 1
+        if (MF == 16) {
+            // k-half 0 column by column; each U fragment is replaced by its k-half-1 successor as soon as its four MFMAs are
+            // issued (the read hides behind the remaining ones), then k-half 1
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < 8; j++) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[j], acc[i][j], 0, 0, 0);
-            const int row = wn * 128 + j * 16 + (lane & 15);
-            fb[j] = *reinterpret_cast<const halfx8 *>(Bcur + row * 128 + swz(row, 4 + chunk0) * 16);
+                for (int i = 0; i < 4; i++)
+                    acc[MF == 16 ? i : 0][MF == 16 ? j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[j], acc[MF == 16 ? i : 0][MF == 16 ? j : 0], 0, 0, 0);
+                const int row = wn * 128 + j * 16 + (lane & 15);
+                fb[j] = *reinterpret_cast<const halfx8 *>(Bcur + row * 128 + swz(row, 4 + chunk0) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc[MF == 16 ? i : 0][MF == 16 ? j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][i], fb[j], acc[MF == 16 ? i : 0][MF == 16 ? j : 0], 0, 0, 0);
+        } else {
+            // k-steps 0 and 1 column by column, each U fragment replaced by its successor two k-steps on as soon as its two MFMAs are
+            // issued; then k-steps 2 and 3.  32 MFMAs of 32 x 32 x 16 per stage instead of 64 of 16 x 16 x 32: with operands in registers
+            // the matrix pipe sustains 1 800 TF on the former and 1 285 on the latter (tools/probe_mfma_sustained.hip).
+#pragma unroll
+            for (int st = 0; st < 2; st++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+                        acc32[MF == 32 ? i : 0][MF == 32 ? j : 0] =
+                            __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][2 * st + i], fb[4 * st + j], acc32[MF == 32 ? i : 0][MF == 32 ? j : 0], 0, 0, 0);
+                    const int row = wn * 128 + j * 32 + (lane & 31);
+                    fb[4 * st + j] = *reinterpret_cast<const halfx8 *>(Bcur + row * 128 + swz(row, 2 * (st + 2) + chunk0) * 16);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the read HERE, behind the MFMAs still to be issued (the scheduler sank it to its use)
+                }
+#pragma unroll
+            for (int st = 0; st < 2; st++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+                        acc32[MF == 32 ? i : 0][MF == 32 ? j : 0] =
+                            __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][2 * st + i], fb[4 * st + j], acc32[MF == 32 ? i : 0][MF == 32 ? j : 0], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][i], fb[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -482,23 +544,36 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
     if (!late) __builtin_amdgcn_s_barrier();
     const double invS = (double)gp.scale[1];
     const bool accum = gp.v0 == nullptr;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const long long col = n0 + wn * 128 + j * 16 + (lane & 15);
-            const double ck = (col < gp.n) ? gp.colsum[col] : 0.0;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const long long row = m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + e;
-                if (row < gp.p && col < gp.ldx) {
-                    float *dst = gp.Xr + row * gp.ldx + col;
-                    const double base = accum ? (double)(*dst) : (double)gp.v0[row] * ck;
-                    const double v = (col < gp.n) ? fma((double)gp.dx[row] * invS, (double)acc[i][j][e], base) : 0.0;
-                    *dst = (float)v;
-                }
-            }
+    auto put = [&](long long row, long long col, double ck, float a) {
+        if (row < gp.p && col < gp.ldx) {
+            float *dst = gp.Xr + row * gp.ldx + col;
+            const double base = accum ? (double)(*dst) : (double)gp.v0[row] * ck;
+            const double v = (col < gp.n) ? fma((double)gp.dx[row] * invS, (double)a, base) : 0.0;
+            *dst = (float)v;
         }
+    };
+    if (MF == 16) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const long long col = n0 + wn * 128 + j * 16 + (lane & 15);
+                const double ck = (col < gp.n) ? gp.colsum[col] : 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) put(m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + e, col, ck, acc[MF == 16 ? i : 0][MF == 16 ? j : 0][e]);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const long long col = n0 + wn * 128 + j * 32 + (lane & 31);
+                const double ck = (col < gp.n) ? gp.colsum[col] : 0.0;
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    put(m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), col, ck, acc32[MF == 32 ? i : 0][MF == 32 ? j : 0][e]);
+            }
+    }
 }
 
 }  // namespace pg
@@ -544,15 +619,24 @@ static int launch_geno_gemm(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep
     gp.v0 = v0; gp.dx = dx; gp.Xr = Xr;
     constexpr int WLDS = 5 * 256 * 128;
     // per device (the attribute belongs to the function object of the current device; contexts of several GPUs share this process)
-    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rotate_geno_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
+    // PG_GENO_MFMA=32 selects the 32 x 32 x 16 instantiation (A/B, tests).  With operands in registers the matrix pipe sustains 1 800 TF
+    // on that shape against 1 285 on 16 x 16 x 32 (tools/probe_mfma_sustained.hip; one wave per SIMD alone: 1 780 against 900), but in this
+    // kernel it is the slower one: 38.9 ms against 31.2 per 100 000 SNPs, MFMA pipe 0.56 busy against 0.74 (tools/ab_rotate_mfma.sh).
+    // A wave of 32 x 32 MFMAs saturates the pipe by itself, so the two waves of a SIMD can no longer fill each other's issue gaps and the
+    // memory phase (LDS-DMA of 48 KB per stage and CU) is exposed instead of hidden.
+    const bool mf16 = !(getenv("PG_GENO_MFMA") && atoi(getenv("PG_GENO_MFMA")) == 32);
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rotate_geno_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rotate_geno_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
     gp.tiles_m = (int)((p + 255) / 256); gp.tiles_n = (int)((n + 255) / 256); gp.KT = (int)kt;
     const long long T = (long long)gp.tiles_m * gp.tiles_n;
     PG_REQUIRE(T < (1LL << 31), "genotype rotation: too many tiles");
     gp.cond = cond; gp.cmode = cond ? COND_PASS1 : COND_ALWAYS;
-    rotate_geno_kernel<<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
+    if (mf16) rotate_geno_kernel<16><<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
+    else rotate_geno_kernel<32><<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
     if (second_pass) {   // Xr += delta * U'ind
         gp.Gt = Gi; gp.v0 = nullptr; gp.dx = dlt; gp.cmode = cond ? COND_PASS2 : COND_ALWAYS;
-        rotate_geno_kernel<<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
+        if (mf16) rotate_geno_kernel<16><<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
+        else rotate_geno_kernel<32><<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
     }
     PG_HIP(hipGetLastError());
     return PG_OK;

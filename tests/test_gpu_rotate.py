@@ -41,10 +41,13 @@ def _geno(rng, n, p, standardise):
     return G.astype(np.float32)
 
 
+@pytest.mark.parametrize("mfma", [16, 32])
 @pytest.mark.parametrize("n,p,std", [(64, 32, True), (257, 130, True), (300, 128, False), (1000, 516, True), (2000, 200, True)])
-def test_rotate_genotype_fast_path(n, p, std, ctx):
-    """fp16x2 genotype path: error vs the fp64 rotation within the fp32-GEMM class (and no worse than the fp32-MFMA path)."""
+def test_rotate_genotype_fast_path(n, p, std, mfma, ctx, monkeypatch):
+    """fp16x2 genotype path: error vs the fp64 rotation within the fp32-GEMM class (and no worse than the fp32-MFMA path) — the
+    shipped kernel on v_mfma_f32_16x16x32_f16 and its 32 x 32 x 16 instantiation (PG_GENO_MFMA=32: measured alternative, slower)."""
     from pygemma_amd import ops
+    monkeypatch.setenv("PG_GENO_MFMA", str(mfma))
     rng = np.random.default_rng(n + p)
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
     U = Q.astype(np.float32)
