@@ -980,9 +980,10 @@ __device__ __forceinline__ void bc_give_up(int *ctl, int *fail, int s, int K)
         ((spins_) > (1 << 20) || __hip_atomic_load(&(ctl_)[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { (bad_) = true; break; }
 
 template <int NWT>      // wavefronts per workgroup: 16 (one workgroup per CU) or 8 (two per CU: matrices of up to 2 x 64 x CUs rows)
-__global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *S, double *VV, double *TAU, int nk, double *mail, int nwg, int *ctl, int *fail)
+__global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *S, double *VV, double *TAU, int nk, double *mail, int nwg, int *ctl, int *fail, int test_fault)
 {
     constexpr int NW = NWT, RW = B / NWT;
+    if (test_fault && blockIdx.x == 1) return;      // tests only (PG_BC_TEST_FAULT=1): a workgroup that never shows up — its neighbours' waits must expire
     extern __shared__ double bc_lds[];
     double *Wn = bc_lds;
     double *vcur = Wn + B * WP, *vprev = vcur + B, *wv = vprev + B, *qv = wv + B;
@@ -1157,8 +1158,9 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
     }
 }
 
-int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2Work &w)
+int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2Work &w, bool allow_stationary, bool *used_stationary)
 {
+    if (used_stationary) *used_stationary = false;
     hipStream_t st = ctx->stream;
     band_extract_kernel<<<(unsigned)(((size_t)(n + 2) * SB_LD + 255) / 256), 256, 0, st>>>(n, A, w.S);
     PG_HIP(hipMemsetAsync(w.prog, 0, ((size_t)n + 16) * sizeof(int), st));
@@ -1184,10 +1186,13 @@ int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2W
         // while 469 blocks, n = 30 000, take 0.21 s — the second workgroup per CU is used up to 15/8 of the CUs)
         bool stationary = nblk <= std::min(per_cu == 1 ? ctx->num_cu : ctx->num_cu * 15 / 8, w.kmax);
         if (const char *e_ = getenv("PG_BC_STATIONARY")) stationary = stationary && atoi(e_) != 0;
+        stationary = stationary && allow_stationary;
+        if (used_stationary) *used_stationary = stationary;
         if (stationary) {
             PG_HIP(hipMemsetAsync(w.mail, 0, (size_t)nblk * MB_LD * 8, st));
-            if (per_cu == 1) bc_stationary_kernel<NW><<<nblk, 64 * NW, BC_LDS, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.mail, nblk, w.prog + n, w.fail);
-            else bc_stationary_kernel<8><<<nblk, 64 * 8, BC_LDS8, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.mail, nblk, w.prog + n, w.fail);
+            const int test_fault = (getenv("PG_BC_TEST_FAULT") && atoi(getenv("PG_BC_TEST_FAULT")) != 0) ? 1 : 0;
+            if (per_cu == 1) bc_stationary_kernel<NW><<<nblk, 64 * NW, BC_LDS, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.mail, nblk, w.prog + n, w.fail, test_fault);
+            else bc_stationary_kernel<8><<<nblk, 64 * 8, BC_LDS8, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.mail, nblk, w.prog + n, w.fail, test_fault);
         } else {
             // a sweep trails the one ahead by two blocks: n / 128 sweeps are in flight at most; workgroups beyond that would only poll
             int nwg = n / (2 * B) + 4;

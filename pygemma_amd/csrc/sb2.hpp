@@ -43,7 +43,7 @@ void sb2_free(Sb2Work &w);
 // A: n x n fp64 full symmetric (row-major, ld n), destroyed: on return its band |i - j| <= SB_B holds the band matrix
 int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w);
 // band of A -> compact storage -> bulge chasing: d (n), e (n - 1) on the device; reflectors in w.VV / w.TAU
-int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2Work &w);
+int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2Work &w, bool allow_stationary = true, bool *used_stationary = nullptr);
 // Z (n x n row-major) <- Q2 Z, then Z <- Q1 Z
 int bt2_prep_device(pg_ctx *ctx, int n, Sb2Work &w, hipStream_t st);   // (V, V T) of every reflector block; st: stream to run on (nullptr: ctx's)
 int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w, bool prepared = false);

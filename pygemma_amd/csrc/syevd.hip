@@ -1312,14 +1312,21 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
     sym_from_lower_kernel<<<(unsigned)(((size_t)n * n + 255) / 256), 256, 0, st>>>(n, n, K, A);
     rc = sy2sb_device(ctx, n, A, sw);
     mark("dense->band");
-    if (!rc) rc = sb2st_device(ctx, n, A, dd, de, sw);
     std::vector<double> hd(n), he(n, 0.0), ev;
     int hfail[4] = {0, 0, 0, 0};
-    if (!rc) {
+    for (int attempt = 0; attempt < 2 && !rc; attempt++) {
+        // second attempt: the stationary bulge-chasing kernel needs every workgroup resident at once; should a wait of its have expired
+        // (CUs masked or taken by someone else), the band is still in A and the kernel that carries the rows through memory takes over
+        bool stationary = false;
+        rc = sb2st_device(ctx, n, A, dd, de, sw, attempt == 0, &stationary);
+        if (rc) break;
         if (hipMemcpyAsync(hd.data(), dd, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipMemcpyAsync(he.data(), de, (size_t)(n - 1) * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipMemcpyAsync(hfail, sw.fail, sizeof(hfail), hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) { set_error("pg_syevd_dev: reading T back failed: %s", hipGetErrorString(hipGetLastError())); rc = PG_EHIP; }
+            hipStreamSynchronize(st) != hipSuccess) { set_error("pg_syevd_dev: reading T back failed: %s", hipGetErrorString(hipGetLastError())); rc = PG_EHIP; break; }
+        if (!(hfail[1] && !hfail[0] && stationary)) break;
+        if (timing) fprintf(stderr, "[pg_syevd_dev 2-stage n=%d] a wait of the stationary bulge chasing expired (sweep %d, block %d): again with the rows through memory\n", n, hfail[2], hfail[3]);
+        if (hipMemsetAsync(sw.fail + 1, 0, 3 * sizeof(int), st) != hipSuccess) { rc = PG_EHIP; break; }
     }
     mark("band->tridiag");
     if (!rc && (hfail[0] || hfail[1])) {

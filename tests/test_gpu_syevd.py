@@ -264,6 +264,21 @@ def test_stage2_back_transformation_one_block_per_trip(n, ctx, monkeypatch):
         b.free()
 
 
+def test_stationary_bulge_chasing_wait_expiry_falls_back_to_the_memory_kernel(ctx, monkeypatch):
+    """PG_BC_TEST_FAULT=1 removes one workgroup of the stationary bulge-chasing kernel: its neighbours' bounded waits expire, the flag is
+    raised (nothing hangs), and pg_syevd_dev repeats stage 2 with the kernel that carries the rows through memory — same answer."""
+    n = 900
+    K = _kin(n, seed=77)
+    K64 = np.tril(K.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
+    monkeypatch.setenv("PG_SYEVD_STAGES", "2")
+    monkeypatch.setenv("PG_BC_TEST_FAULT", "1")
+    from pygemma_amd import ops
+    ev32, U32, ev, U = ops.syevd(K, ctx=ctx, want64=True)
+    assert np.abs(U.T @ U - np.eye(n)).max() <= 1e-12
+    assert np.linalg.norm(K64 - (U * ev) @ U.T) / np.linalg.norm(K64) <= 1e-12 * np.sqrt(n)
+    assert np.abs(ev - np.linalg.eigvalsh(K64)).max() <= 1e-12 * np.abs(ev).max()
+
+
 def test_two_stage_flags_a_rank_deficient_panel(ctx):
     """A K whose first panel has dependent columns: stage 1 must raise its flag (pg_syevd_dev then takes the one-stage path)."""
     from pygemma_amd import _lib
