@@ -557,13 +557,11 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
 {
     hipStream_t st = ctx->stream;
     constexpr int LDS4 = 4 * MAT * 8, CHOL_LDS = (2 * MAT + B) * 8;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recon_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
-        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
-        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CHOL_LDS));
-        attr_done = true;
-    }
+    // the dynamic-LDS limit is a per-DEVICE property of the function: set on every call (a few microseconds, once per solve), never
+    // cached per process — a second device in the same process would launch these kernels without it
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recon_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CHOL_LDS));
     PG_HIP(hipMemsetAsync(w.Vst, 0, (size_t)n * n * 8, st));
     PG_HIP(hipMemsetAsync(w.Tst, 0, (size_t)(w.npan + 1) * B * B * 8, st));
     PG_HIP(hipMemsetAsync(w.fail, 0, 4 * sizeof(int), st));
@@ -1168,13 +1166,10 @@ int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2W
     PG_HIP(hipMemsetAsync(w.TAU, 0, (size_t)n * w.nk * 8, st));
     if (n >= 3) {
         constexpr int BC_LDS = BC_LDS_BYTES, BC_LDS8 = (B * WP + 4 * B + 2 * 8 * B + 4) * 8;
-        static bool attr_done = false;
-        if (!attr_done) {
-            PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS));
-            PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_stationary_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS));
-            PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_stationary_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS8));
-            attr_done = true;
-        }
+        // per device, on every call (see sy2sb_device)
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS));
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_stationary_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS));
+        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_stationary_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS8));
         // one workgroup per block of 64 rows, all of them resident at once (they wait for each other): one per CU with 16 wavefronts,
         // two per CU with 8 (76 KB of LDS each; a step's busy time 5.2 instead of 4.9 us); larger matrices take the kernel that carries
         // the rows through memory.  Should the grid not become resident after all, the bounded waits raise the flag and the caller
@@ -1185,6 +1180,16 @@ int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2W
         // (with every CU holding two workgroups the sweep period doubles: 512 row blocks 0.47 s against 0.40 s for the memory kernel at 513,
         // while 469 blocks, n = 30 000, take 0.21 s — the second workgroup per CU is used up to 15/8 of the CUs)
         bool stationary = nblk <= std::min(per_cu == 1 ? ctx->num_cu : ctx->num_cu * 15 / 8, w.kmax);
+        // every workgroup waits for its neighbours, so the whole grid has to be resident: ask the runtime how many workgroups of this
+        // kernel (its registers, its LDS) one CU takes instead of assuming it from the CU count alone
+        if (stationary) {
+            int occ = 0;
+            const hipError_t oe = (per_cu == 1)
+                ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bc_stationary_kernel<NW>, 64 * NW, (size_t)BC_LDS)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, bc_stationary_kernel<8>, 64 * 8, (size_t)BC_LDS8);
+            if (oe != hipSuccess) { (void)hipGetLastError(); occ = 0; }
+            stationary = occ >= per_cu && (long long)nblk <= (long long)std::min(occ, per_cu) * ctx->num_cu;
+        }
         if (const char *e_ = getenv("PG_BC_STATIONARY")) stationary = stationary && atoi(e_) != 0;
         stationary = stationary && allow_stationary;
         if (used_stationary) *used_stationary = stationary;
@@ -1661,13 +1666,10 @@ int bt2_prep_device(pg_ctx *ctx, int n, Sb2Work &w, hipStream_t st)
     if (!st) st = ctx->stream;
     constexpr int VR = 128;
     const size_t lds = (size_t)(VR * P65 + 2 * MAT) * 8;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS_BYTES));
-        PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_apply4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS_BYTES));
-        attr_done = true;
-    }
+    // per device, on every call (see sy2sb_device)
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS_BYTES));
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_apply4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS_BYTES));
     bt2_prep_kernel<<<dim3(w.ng, w.kmax), 256, lds, st>>>(n, w.nk, w.ng, w.VV, w.TAU, w.Vp, w.Vtp);
     PG_HIP(hipGetLastError());
     return PG_OK;

@@ -423,3 +423,36 @@ if __name__ == "__main__" and "degenerate" in sys.argv[1:]:
 if __name__ == "__main__" and "eigen_big" in sys.argv[1:]:
     for nn in (2000, 10000):
         gen_eigen_true_big(nn)
+
+
+def _crc(a):
+    import zlib
+    return np.int64(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+def gen_tier_a_big():
+    """Tier A at the configs' n: the REAL reference with eigen=False (experiments/large_gwas/run_pygemma.py:57-65 is the
+    caller of that entry, lmm/lmm.py:164-167) on synth.fast_rotated_panel(n, p, c, seed) inputs, which the GPU box regenerates from the
+    seed (CRC-32 of d, X, Y, W stored and asserted there).  Stored: seed, shape, the six output columns per lambda path."""
+    import time
+    cases = [("n10000_c5", 10000, 32, 5, 910005, (False, True)),      # configs[2]
+             ("n10000_c10", 10000, 32, 10, 910010, (False, True)),    # configs[3], per-GPU kernel shape
+             ("n50000_c5", 50000, 8, 5, 950005, (True,))]             # configs[4]: grid path only
+    out = {"versions": VERS, "cases": np.array([c[0] for c in cases])}
+    for tag, n, p, c, seed, grids in cases:
+        rp = synth.fast_rotated_panel(n, p, c, seed=seed)
+        out[f"{tag}_shape"] = np.array([n, p, c, seed], np.int64)
+        out[f"{tag}_crc"] = np.array([_crc(rp["d"]), _crc(rp["X"]), _crc(rp["Y"]), _crc(rp["W"])], np.int64)
+        for grid in grids:
+            t = time.time()
+            df = quiet(ref.pygemma, rp["Y"], rp["X"], rp["W"], rp["d"], grid=grid, eigen=False, nproc=1)
+            print(f"  reference {tag} grid={grid}: {time.time() - t:.1f} s", flush=True)
+            for col in ["beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"]:
+                out[f"{tag}_{'grid' if grid else 'brent'}_{col}"] = df[col].to_numpy()
+    name = "tier_a_config_sizes.npz"
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+
+
+if __name__ == "__main__" and "tier_a_big" in sys.argv[1:]:
+    gen_tier_a_big()

@@ -44,6 +44,35 @@ def test_config_shapes_bit_exact_vs_oracle(n, c, grid, p, ctx):
         assert bad.mean() <= 0.02, bad.sum()
 
 
+@pytest.mark.parametrize("tag", ["n10000_c5", "n10000_c10", "n50000_c5"])
+def test_config_shapes_vs_the_real_reference(tag, ctx):
+    """Tier A at the configs' n against the REFERENCE ITSELF, not only the oracle: tests/golden/tier_a_config_sizes.npz
+    holds the six columns the real reference returned with eigen=False (lmm/lmm.py:164-167; experiments/large_gwas/run_pygemma.py:57-65)
+    at n = 10 000 (c = 5 and 10, Brent and grid) and n = 50 000 (grid) on inputs regenerated here from a seed (CRC-checked).
+    Bar: >= 99 % of the rows bit-identical in every column, the rest inside the Tier-A tolerances, p within 1e-8."""
+    import os
+    import zlib
+    from pygemma_amd import ops, synth
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tier_a_config_sizes.npz"))
+    n, p, c, seed = (int(v) for v in z[f"{tag}_shape"])
+    rp = synth.fast_rotated_panel(n, p, c, seed=seed)
+    crc = [zlib.crc32(np.ascontiguousarray(rp[k]).tobytes()) for k in ("d", "X", "Y", "W")]
+    assert crc == [int(v) for v in z[f"{tag}_crc"]], "inputs do not regenerate from the seed"
+    for path in ("brent", "grid"):
+        if f"{tag}_{path}_beta" not in z.files:
+            continue
+        got = ops.assoc(rp["d"], rp["W"], rp["Y"], rp["X"], grid=(path == "grid"), ctx=ctx)
+        rowbad = np.zeros(p, bool)
+        for col in ["beta", "se_beta", "tau", "lambda", "F_wald"]:
+            ref = z[f"{tag}_{path}_{col}"]
+            rowbad |= bits(np.asarray(got[col]).astype(ref.dtype)) != bits(ref)
+        assert rowbad.mean() <= 0.01, (tag, path, int(rowbad.sum()))
+        np.testing.assert_allclose(got["p_wald"], z[f"{tag}_{path}_p_wald"], rtol=1e-8)
+        for col, tol in (("beta", 1e-4), ("se_beta", 1e-4), ("tau", 1e-4), ("lambda", 2e-5), ("F_wald", 2e-4)):
+            np.testing.assert_allclose(np.asarray(got[col], np.float64)[rowbad], np.asarray(z[f"{tag}_{path}_{col}"], np.float64)[rowbad],
+                                       rtol=tol, err_msg=col)
+
+
 def test_results_do_not_depend_on_batching_or_snp_position(ctx):
     """Property: each SNP's row depends only on that SNP (lmm.py:466-483) — permuting / re-batching the columns
     permutes the rows bit-for-bit (exercises every wave slot of the workgroups at n = 10 000)."""

@@ -290,3 +290,35 @@ def test_two_stage_flags_a_rank_deficient_panel(ctx):
     _lib.check(L.pgx_sb2_stage1_dev(ctx.handle, n, dK.ptr, dA.ptr, None, flags), "stage 1")
     assert flags[0] != 0
     dK.free(); dA.free()
+
+
+def test_two_stage_solve_on_the_last_device_after_device_zero():
+    """Per-device state: the kernels of the two-stage solver that need more than 64 KB of dynamic LDS carry that limit
+    as a per-DEVICE function attribute.  One process solves on device 0, then on the LAST visible device: the second solve must launch
+    with the attribute set on that device too and satisfy the same invariants.  Skips below two GPUs."""
+    from pygemma_amd import _lib, ops
+    ndev = _lib.device_count()
+    if ndev < 2:
+        pytest.skip("needs two visible GPUs")
+    n = 832
+    K = _kin(n, seed=4242)
+    K64 = np.tril(K.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
+    ref = np.linalg.eigvalsh(K64)
+    import os
+    old = os.environ.get("PG_SYEVD_STAGES")
+    os.environ["PG_SYEVD_STAGES"] = "2"
+    try:
+        for dev in (0, ndev - 1):
+            c = _lib.Context(dev)
+            try:
+                ev32, U32, ev, U = ops.syevd(K, ctx=c, want64=True)
+            finally:
+                c.close()
+            assert np.abs(ev - ref).max() <= 1e-12 * np.abs(ref).max(), f"device {dev}"
+            assert np.abs(U.T @ U - np.eye(n)).max() <= 1e-12, f"device {dev}"
+            assert np.linalg.norm(K64 - (U * ev) @ U.T) / np.linalg.norm(K64) <= 1e-12 * np.sqrt(n), f"device {dev}"
+    finally:
+        if old is None:
+            os.environ.pop("PG_SYEVD_STAGES", None)
+        else:
+            os.environ["PG_SYEVD_STAGES"] = old

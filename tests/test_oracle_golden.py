@@ -290,3 +290,37 @@ def test_degenerate_panels_vs_reference(grid, order):
             assert same.all(), (tag, col, np.nonzero(~same)[0], a[~same][:3], r[~same][:3])
             compared += int(keep.sum())
     assert compared >= 15 * 11 * 6
+
+
+def _tier_a_cases():
+    z = np.load(os.path.join(G, "tier_a_config_sizes.npz"))
+    return z, [str(t) for t in z["cases"]]
+
+
+def _tier_a_inputs(z, tag):
+    """Regenerates the fixture's inputs from its seed and checks them byte for byte (CRC-32) against what the reference was given."""
+    import zlib
+    from pygemma_amd import synth
+    n, p, c, seed = (int(v) for v in z[f"{tag}_shape"])
+    rp = synth.fast_rotated_panel(n, p, c, seed=seed)
+    crc = [zlib.crc32(np.ascontiguousarray(rp[k]).tobytes()) for k in ("d", "X", "Y", "W")]
+    assert crc == [int(v) for v in z[f"{tag}_crc"]], "synth.fast_rotated_panel no longer regenerates the fixture's inputs"
+    return rp, n, p, c
+
+
+@pytest.mark.parametrize("tag", ["n10000_c5", "n10000_c10", "n50000_c5"])
+def test_oracle_equals_the_reference_at_the_configs_n(tag):
+    """Tier A at BASELINE.json's sizes: the reference itself (eigen=False, lmm/lmm.py:164-167; caller
+    experiments/large_gwas/run_pygemma.py:57-65) was run at n = 10 000 (c = 5, 10; Brent and grid) and n = 50 000 (grid); the oracle in
+    the reference's summation order reproduces every row bit for bit, p within 1e-9."""
+    z, _ = _tier_a_cases()
+    rp, n, p, c = _tier_a_inputs(z, tag)
+    for path in ("brent", "grid"):
+        if f"{tag}_{path}_beta" not in z.files:
+            continue
+        orc = O.calculate(rp["d"], rp["Y"], rp["W"], rp["X"], grid=(path == "grid"), order=0, nthreads=8)
+        for col in ("beta", "se_beta", "tau", "lambda", "F_wald"):
+            ref = z[f"{tag}_{path}_{col}"]
+            bad = int((bits(orc[col].astype(ref.dtype)) != bits(ref)).sum())
+            assert bad == 0, (tag, path, col, bad)
+        np.testing.assert_allclose(orc["p_wald"], z[f"{tag}_{path}_p_wald"], rtol=1e-9, atol=0)
