@@ -227,6 +227,12 @@ int pg_kinship_dev(pg_ctx *ctx, int64_t n, int64_t p_k, const float *Gt, int64_t
  * mirror, bit-symmetric).  K can go straight into pg_syevd_dev. */
 int pg_kinship_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *G, int64_t ldG, int standardize, float *K);
 
+/* ---- lmm/lmm.py:124-125: K <- Z K Z' for the optional design matrix Z (n x q) of the random effect, K (q x q).  Z and K may each be
+ * float32 or float64 (z_is_f64 / k_is_f64), row-major with row strides ldz / ldk, on the device; out = float32 (n x n, row stride ldo),
+ * what lmm.py:127-128 hands to the eigensolver.  Two fp64-MFMA products and one rounding. */
+int pg_zkzt_dev(pg_ctx *ctx, int64_t n, int64_t q, const void *Z, int z_is_f64, int64_t ldz, const void *K, int k_is_f64, int64_t ldk,
+                float *out, int64_t ldo);
+
 /* ---- H1: eigendecomposition of K (lmm/lmm.py:151-162 / :196-207, scipy.linalg.eigh = LAPACK ssyevr)
  * Reads the LOWER triangle of row-major K (n x n, float32, device).  Computes in fp64; delivers ascending
  * eigenvalues clamped at 0 (lmm/lmm.py:157) as float32, and U (column j = eigenvector j) as float32
@@ -269,6 +275,10 @@ int pg_ml_scalars_dev(pg_ctx *ctx, int64_t n, const float *args7, float *out3);
  * pgx_stedc_dev : divide & conquer on a tridiagonal given on the host -> eigenvalues (host), eigenvectors Z (device) */
 int pgx_dgemm_dev(pg_ctx *ctx, int transA, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
                   const double *B, int64_t ldb, double beta, double *C, int64_t ldc);
+/* pgx_dgemm_ex_dev: every mode of that GEMM: flags bit 0 transA, bit 1 transB (B stored N x K), bit 2 lower triangle of C only,
+ * bit 3 A symmetric (lower triangle + full diagonal tiles valid), bit 4 no split-K; kxorB: B's k index XOR-ed (multiple of 8) */
+int pgx_dgemm_ex_dev(pg_ctx *ctx, int flags, int kxorB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                     const double *B, int64_t ldb, double beta, double *C, int64_t ldc);
 int pgx_sytrd_dev(pg_ctx *ctx, int64_t n, const float *K, double *d, double *e, double *tau, double *Vall);
 int pgx_stedc_dev(pg_ctx *ctx, int64_t n, const double *d_host, const double *e_host, double *evals_host, double *Z_dev);
 /* The two-stage tridiagonalisation of pg_syevd_dev (csrc/sb2.hip), one stage at a time (all matrices n x n fp64 row-major on the device):

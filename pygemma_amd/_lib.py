@@ -23,6 +23,7 @@ SYMBOLS = [
     "pg_comm_unique_id", "pg_comm_init_rank", "pg_comm_init_all", "pg_comm_destroy", "pg_comm_size", "pg_comm_rank",
     "pg_comm_broadcast_dev", "pg_comm_allgather_dev", "pg_comm_allreduce_f64_dev", "pg_comm_barrier", "pg_comm_group_start",
     "pg_comm_group_end", "pgx_dgemm_dev", "pgx_sytrd_dev", "pgx_stedc_dev", "pgx_sb2_stage1_dev", "pgx_sb2_stage2_dev", "pgx_sb2_set_debug", "pg_kinship_geno_dev", "pg_assoc_lrt_dev", "pg_rotate_auto_dev", "pg_assoc_set_eval_trace", "pg_rotate_auto_i8_dev",
+    "pg_zkzt_dev", "pgx_dgemm_ex_dev",
 ]
 
 
@@ -125,6 +126,10 @@ def load():
     L.pg_comm_allreduce_f64_dev.argtypes = [vp, vp, sz, i32]
     L.pg_comm_barrier.argtypes = [vp]
     L.pgx_dgemm_dev.argtypes = [vp, i32, i64, i64, i64, C.c_double, vp, i64, vp, i64, C.c_double, vp, i64]
+    L.pgx_dgemm_ex_dev.argtypes = [vp, i32, i32, i64, i64, i64, C.c_double, vp, i64, vp, i64, C.c_double, vp, i64]
+    L.pgx_dgemm_ex_dev.restype = i32
+    L.pg_zkzt_dev.argtypes = [vp, i64, i64, vp, i32, i64, vp, i32, i64, vp, i64]
+    L.pg_zkzt_dev.restype = i32
     L.pgx_sytrd_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     L.pgx_stedc_dev.argtypes = [vp, i64, vp, vp, vp, vp]
     L.pgx_sb2_stage1_dev.argtypes = [vp, i64, vp, vp, vp, vp]

@@ -1042,6 +1042,68 @@ extern "C" int pgx_dgemm_dev(pg_ctx *ctx, int transA, int64_t M, int64_t N, int6
     return dgemm(ctx, transA != 0, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
 }
 
+// every mode of the fp64 GEMM behind one test hook: flags bit 0 transA (A stored K x M), bit 1 transB (B stored N x K), bit 2 lower_only
+// (C symmetric, tiles above the diagonal skipped), bit 3 symA (A symmetric, lower triangle + full 128 x 128 diagonal tiles valid),
+// bit 4 no split-K; kxorB: B's k index XOR-ed (multiple of 8)
+extern "C" int pgx_dgemm_ex_dev(pg_ctx *ctx, int flags, int kxorB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
+                                const double *B, int64_t ldb, double beta, double *C, int64_t ldc)
+{
+    PG_REQUIRE(ctx && A && B && C, "pgx_dgemm_ex_dev: NULL argument");
+    PG_HIP(hipSetDevice(ctx->device));
+    DgemmDesc d;
+    d.transA = (flags & 1) != 0; d.transB = (flags & 2) != 0; d.lower_only = (flags & 4) != 0; d.symA = (flags & 8) != 0;
+    d.allow_splitk = (flags & 16) == 0; d.kxorB = kxorB;
+    d.M = M; d.N = N; d.K = K; d.alpha = alpha; d.beta = beta; d.A = A; d.lda = lda; d.B = B; d.ldb = ldb; d.C = C; d.ldc = ldc;
+    return dgemm_ex(ctx, d);
+}
+
+// ---- lmm/lmm.py:124-125  K <- Z K Z'  (Z: n x q, K: q x q; float32 or float64 each) on the device ----------------------------------
+// Two fp64-MFMA products, T = Z K and R = T Z', and ONE rounding to float32 at the end (the reference rounds once per float32 BLAS
+// product when both inputs are float32, or once at lmm.py:127-128 when one is float64: either way the result below is within one
+// float32 rounding of the exact product, which is at least as close as the reference's own).
+static __global__ void widen_kernel(int64_t rows, int64_t cols, const void *src, int is64, int64_t ld, double *dst)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int64_t r = idx / cols, c = idx % cols;
+    dst[idx] = is64 ? static_cast<const double *>(src)[r * ld + c] : (double)static_cast<const float *>(src)[r * ld + c];
+}
+static __global__ void narrow_kernel(int64_t rows, int64_t cols, const double *src, float *dst, int64_t ld)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    dst[(idx / cols) * ld + idx % cols] = (float)src[idx];
+}
+extern "C" int pg_zkzt_dev(pg_ctx *ctx, int64_t n, int64_t q, const void *Z, int z_is_f64, int64_t ldz, const void *K, int k_is_f64,
+                           int64_t ldk, float *out, int64_t ldo)
+{
+    PG_REQUIRE(ctx && Z && K && out && n > 0 && q > 0 && ldz >= q && ldk >= q && ldo >= n, "pg_zkzt_dev: bad arguments");
+    PG_HIP(hipSetDevice(ctx->device));
+    double *Zd = nullptr, *Kd = nullptr, *T = nullptr, *R = nullptr;
+    int rc = alloc_d(&Zd, (size_t)n * q);
+    if (!rc) rc = alloc_d(&Kd, (size_t)q * q);
+    if (!rc) rc = alloc_d(&T, (size_t)n * q);
+    if (!rc) rc = alloc_d(&R, (size_t)n * n);
+    hipStream_t st = ctx->stream;
+    if (!rc) {
+        widen_kernel<<<(unsigned)((n * q + 255) / 256), 256, 0, st>>>(n, q, Z, z_is_f64, ldz, Zd);
+        widen_kernel<<<(unsigned)((q * q + 255) / 256), 256, 0, st>>>(q, q, K, k_is_f64, ldk, Kd);
+        rc = dgemm(ctx, false, n, q, q, 1.0, Zd, q, Kd, q, 0.0, T, q);             // T = Z K
+    }
+    if (!rc) {
+        DgemmDesc d;                                                              // R = T Z'  (B = Z stored N x K)
+        d.transB = true; d.M = n; d.N = n; d.K = q; d.alpha = 1.0; d.beta = 0.0; d.A = T; d.lda = q; d.B = Zd; d.ldb = q; d.C = R; d.ldc = n;
+        rc = dgemm_ex(ctx, d);
+    }
+    if (!rc) {
+        narrow_kernel<<<(unsigned)((n * n + 255) / 256), 256, 0, st>>>(n, n, R, out, ldo);
+        if (hipGetLastError() != hipSuccess) rc = PG_EHIP;
+    }
+    (void)hipStreamSynchronize(st);
+    dev_free(Zd); dev_free(Kd); dev_free(T); dev_free(R);
+    return rc;
+}
+
 extern "C" int pgx_sytrd_dev(pg_ctx *ctx, int64_t n64, const float *K, double *d, double *e, double *tau, double *Vall)
 {
     PG_REQUIRE(ctx && K && d && e && tau && Vall && n64 >= 2 && n64 <= 65536, "pgx_sytrd_dev: bad arguments");

@@ -471,6 +471,27 @@ def kinship(G, standardize=True, device=0):
         return dK.download((n, n), np.float32)
 
 
+def _zkzt(L, Z, K):
+    """K <- Z K Z' (lmm/lmm.py:124-125) on GPU 0: Z (n, q), K (q, q), float32 or float64 each; returns the float32 (n, n) matrix that
+    lmm.py:127-128 would hand to the eigensolver.  The reference does this as host BLAS products (4e12 flops at n = q = 10 000)."""
+    if Z.ndim != 2 or K.ndim != 2 or K.shape[0] != K.shape[1] or Z.shape[1] != K.shape[0]:
+        raise ValueError(f"Z {Z.shape} and K {K.shape} do not multiply as Z K Z'")
+    def dev_ready(a):
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float64)
+        return np.ascontiguousarray(a)
+    Z, K = dev_ready(Z), dev_ready(K)
+    n, q = Z.shape
+    with _lib.Context(0) as ctx:
+        dZ, dK, dO = ctx.to_device(Z), ctx.to_device(K), ctx.alloc(n * n * 4)
+        _lib.check(L.pg_zkzt_dev(ctx.handle, n, q, dZ.ptr, int(Z.dtype == np.float64), q, dK.ptr, int(K.dtype == np.float64), q, dO.ptr, n),
+                   "pg_zkzt_dev")
+        out = dO.download((n, n), np.float32)
+        for b_ in (dZ, dK, dO):
+            b_.free()
+    return out
+
+
 def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=False, grid=False, eigen=True, nproc=1,
             checkpoint=None, lrt=False, eigenpairs=None, stats=None):
     """Per-SNP LMM association scan (GEMMA-style REML + Wald test) — signature of lmm/lmm.py:87.
@@ -515,7 +536,7 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
         X = X.astype(np.float32)                             # lmm.py:121-122
     if eigenpairs is None:
         if Z is not None:
-            K = np.asarray(Z) @ K @ np.asarray(Z).T          # lmm.py:124-125
+            K = _zkzt(L, np.asarray(Z), K)                   # lmm.py:124-125, on GPU 0 (two fp64-MFMA products, one rounding to float32)
         k64 = eigen and K.dtype == np.float64                # rounded to float32 on the device instead (same values, no host copy)
         if K.dtype != np.float32 and not k64:
             K = K.astype(np.float32)                         # lmm.py:127-128

@@ -435,9 +435,9 @@ def gen_tier_a_big():
     caller of that entry, lmm/lmm.py:164-167) on synth.fast_rotated_panel(n, p, c, seed) inputs, which the GPU box regenerates from the
     seed (CRC-32 of d, X, Y, W stored and asserted there).  Stored: seed, shape, the six output columns per lambda path."""
     import time
-    cases = [("n10000_c5", 10000, 32, 5, 910005, (False, True)),      # configs[2]
-             ("n10000_c10", 10000, 32, 10, 910010, (False, True)),    # configs[3], per-GPU kernel shape
-             ("n50000_c5", 50000, 8, 5, 950005, (True,))]             # configs[4]: grid path only
+    cases = [("n10000_c5", 10000, 128, 5, 910005, (False, True)),     # configs[2]
+             ("n10000_c10", 10000, 128, 10, 910010, (False, True)),   # configs[3], per-GPU kernel shape
+             ("n50000_c5", 50000, 16, 5, 950005, (True,))]            # configs[4]: grid path only
     out = {"versions": VERS, "cases": np.array([c[0] for c in cases])}
     for tag, n, p, c, seed, grids in cases:
         rp = synth.fast_rotated_panel(n, p, c, seed=seed)

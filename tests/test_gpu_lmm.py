@@ -323,3 +323,31 @@ def test_pygemma_full_pipeline_degenerate_relatedness_matrices(kind):
         assert np.isfinite(b).all() and np.isfinite(t).all()
         assert (np.abs(b - t) / se).max() < 1e-3, (kind, grid, (np.abs(b - t) / se).max())
         np.testing.assert_allclose(df["p_wald"].to_numpy(), tr["p_wald"], rtol=2e-3)
+
+
+@pytest.mark.parametrize("zdt,kdt", [(np.float32, np.float32), (np.float64, np.float32), (np.float32, np.float64)])
+def test_design_matrix_Z_on_the_device(zdt, kdt):
+    """lmm/lmm.py:124-125: K <- Z K Z' with a NON-SQUARE Z (n = 500 samples, q = 300 random-effect levels) on the device
+    (pg_zkzt_dev: two fp64-MFMA products, one rounding): within one float32 rounding of the float64 product — and
+    lmm.pygemma(..., Z=Z) is, bit for bit, lmm.pygemma on that matrix."""
+    import ctypes as C
+    from pygemma_amd import _lib, lmm, synth
+    n, q, p, c = 500, 300, 40, 3
+    rng = np.random.default_rng(11)
+    Kq = synth.panel(q, 4, 1, seed=5)["K"].astype(kdt)
+    Z = np.zeros((n, q), zdt)
+    Z[np.arange(n), rng.integers(0, q, n)] = 1.0                 # incidence matrix: sample i belongs to level z_i
+    Z += (0.05 * rng.standard_normal((n, q))).astype(zdt)        # ... made dense so that every product term counts
+    L = _lib.load()
+    got = lmm._zkzt(L, Z, Kq)
+    exact = Z.astype(np.float64) @ Kq.astype(np.float64) @ Z.astype(np.float64).T
+    assert got.dtype == np.float32 and got.shape == (n, n)
+    assert np.abs(got.astype(np.float64) - exact).max() <= 2.0 ** -23 * np.abs(exact).max()
+    assert (np.abs(got.astype(np.float64) - exact) <= 2.0 ** -23 * np.abs(exact) + 1e-30).mean() >= 0.999
+    raw = synth.panel(n, p, c, seed=21)
+    a = lmm.pygemma(raw["Y"], raw["X"], raw["W"], Kq, Z=Z)
+    b = lmm.pygemma(raw["Y"], raw["X"], raw["W"], got)
+    for col in ("beta", "se_beta", "tau", "lambda", "F_wald", "p_wald"):
+        assert (a[col].to_numpy() == b[col].to_numpy()).all(), col
+    with pytest.raises(ValueError):
+        lmm.pygemma(raw["Y"], raw["X"], raw["W"], Kq, Z=Z[:, :-1])

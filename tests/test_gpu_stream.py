@@ -262,3 +262,42 @@ def test_mem_info_reports_the_device():
         free1, _ = ctx.mem_info()
         assert free0 - free1 >= (1 << 30) - (64 << 20)
         buf.free()
+
+
+def test_config4_one_gpu_share_n10000_c10_p125000_streamed():
+    """BASELINE configs[3], the share of ONE of its 8 GPUs exactly as written: n = 10 000, c = 10, p = 1 000 000 / 8 = 125 000
+    pre-rotated float32 SNP columns (5 GB in pinned host memory) through lmm.pygemma(eigen=False), Brent path (lmm/lmm.py:413-436:
+    SampleIter's block of one worker).  Every row finite; 64 sampled rows — the structured columns, both sides of every batch seam,
+    random ones — bit for bit the oracle's (kernel summation order); SNP order = column order across the seams; prints SNPs/s."""
+    import time
+    from oracle import oracle as O
+    from pygemma_amd import lmm, synth
+    n, p, c = 10000, 125000, 10
+    rp = synth.fast_rotated_panel(n, 64, c, seed=1010)
+    rng = np.random.default_rng(1011)
+    X = lmm.pinned_empty((n, p), np.float32)
+    for s in range(0, p, 5000):
+        X[:, s:s + 5000] = rng.standard_normal((n, 5000), dtype=np.float32)
+    X[:, :64] = rp["X"]
+    # a marker column repeated on both sides of every seam would hide a misplaced batch: instead every sampled column is unique and
+    # the oracle is fed with exactly the columns whose rows are compared
+    st = {}
+    t = time.time()
+    df = lmm.pygemma(rp["Y"], X, rp["W"], rp["d"], eigen=False, stats=st)
+    dt = time.time() - t
+    pb, _ = lmm._batch_geometry(n, 0, p)
+    assert st["batches"] == -(-p // pb) and st["pinned_input"] and st["bytes_in"] == n * p * 4
+    print(f"\\nconfigs[3] one-GPU share: {p} SNPs, n = {n}, c = {c}: {dt:.3f} s = {p / dt / 1e6:.3f} M SNPs/s "
+          f"({st['batches']} batches of {pb}; loop {st.get('blocks_s', float('nan')):.3f} s)")
+    assert len(df) == p
+    for col in COLS:
+        assert np.isfinite(df[col].to_numpy()).all(), col
+    assert (df["p_wald"].to_numpy() <= 1).all() and (df["p_wald"].to_numpy() >= 0).all()
+    seams = np.arange(pb, p, pb)
+    idx = np.unique(np.concatenate([np.arange(12), seams - 1, seams, [p - 2, p - 1], rng.integers(64, p, 64)]))[:64 + 12]
+    idx = idx[np.argsort(rng.random(idx.size))][:64]
+    idx.sort()
+    orc = O.calculate(rp["d"], rp["Y"], rp["W"], np.ascontiguousarray(X[:, idx]), grid=False, order=1, nthreads=16)
+    for col in COLS[:5]:
+        assert (bits(df[col].to_numpy()[idx]) == bits(orc[col].astype(df[col].dtype))).all(), col
+    np.testing.assert_allclose(df["p_wald"].to_numpy()[idx], orc["p_wald"], rtol=1e-9)
