@@ -19,6 +19,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace pg {
 
@@ -258,6 +259,306 @@ __global__ __launch_bounds__(256, 2) void dgemm_kernel(DgemmParams gp)
         }
 }
 
+// ==== LDS-DMA ring kernel =========================================================================================================
+// The same 128 x (32 WNI) tile and MFMA arrangement, but the operands reach LDS by global_load_lds_dwordx4 (no staging registers, no
+// ds_write pass) into a ring of RS = 4 slots of RBK = 8 k-rows: the DMA of chunk t + 3 is issued while chunk t is multiplied, so
+// three chunks (~6 000 cycles of fp64 MFMA) cover the memory latency — the register-staged kernel above prefetches ONE chunk (~2 000
+// cycles, less than a loaded HBM round trip) and stalls its whole workgroup at every barrier.  One raw s_barrier per chunk, counted
+// vmcnt waits (the DMA stays in flight across barriers).  B is always K x N row-major ("k-major"); A is k-major (AKM: stored K x M)
+// or m-major (stored M x K); SYM: A symmetric from its lower triangle — chunks left of / on the diagonal tile are read m-major,
+// chunks right of it k-major from the transposed position.
+// LDS images (all conflict-free for the ds_read_b64 fragment reads, lane = (l & 15) element x (l >> 4) k-row):
+//   k-major operand: row k of the chunk = 1 KB (128 doubles; 512 B for a 64-wide B), 16-byte chunk c of the row holds global chunk
+//                    c ^ 8 (k & 1): odd k-rows are rotated by 128 bytes, so the two k-rows one lane group reads sit on different bank halves
+//   m-major operand: row m = 64 bytes (8 k), 16-byte chunk c holds global k-pair c ^ ((m >> 2) & 3)
+// The swizzles are applied on the GLOBAL address of each lane's 16 bytes (the LDS side of an LDS-DMA is lane-linear).
+// The C tile rides the same ring: after the last operand chunk the next virtual chunks are the tile's 8 groups of 16 rows (16 KB = one
+// slot), prefetched three iterations ahead while the last products run; each group is updated in LDS from the accumulators and leaves
+// in whole rows, 16 bytes per lane.  (The depth-128 update of the band reduction spent as long in its epilogue as in its products.)
+constexpr int RBK = 8, RS = 4;
+
+__device__ __forceinline__ void ring_wait_vm(int n)
+{
+    switch (n) {       // s_waitcnt needs an immediate
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    }
+}
+__device__ __forceinline__ void ring_dma16(const double *src, unsigned char *dst)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+}
+
+template <bool AKM, bool SYM, int WNI>
+__global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
+{
+    constexpr int DBM = 128, DBN = 32 * WNI;
+    constexpr int BROW = DBN * 8;                       // bytes of one k-row of the B image (and of one row of a staged C group)
+    constexpr int SLOT_A = 8192, SLOT = SLOT_A + RBK * BROW;
+    constexpr int NI = (WNI == 4) ? 4 : 3;              // DMA instructions per wave and operand chunk
+    constexpr int NC = (WNI == 4) ? 4 : 2;              // ... per staged C group, and global stores per wave and group
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[RS * SLOT];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long M = gp.M, N = gp.N;
+    // tile of this workgroup: XCD-contiguous remap of the launch index (workgroups b and b + 8 share an XCD's L2), then row-major —
+    // or, for a symmetric update, the enumeration of the lower triangle
+    const int tiles_m = (int)((M + DBM - 1) / DBM), tiles_n = (int)((N + DBN - 1) / DBN);
+    const int T = gp.lower ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+    int tm, tn;
+    {
+        const int b = blockIdx.x, q = T / 8, r = T % 8, xcd = b % 8;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+        if (gp.lower) {
+            int t_ = (int)((sqrt(8.0 * (double)lid + 1.0) - 1.0) * 0.5);
+            while ((t_ + 1) * (t_ + 2) / 2 <= lid) t_++;
+            while (t_ * (t_ + 1) / 2 > lid) t_--;
+            tm = t_; tn = lid - t_ * (t_ + 1) / 2;
+        } else { tm = lid / tiles_n; tn = lid % tiles_n; }
+    }
+    const long long m0 = (long long)tm * DBM, n0 = (long long)tn * DBN;
+    const long long kbeg = (gp.ksplit > 1) ? (long long)blockIdx.y * gp.kchunk : 0;
+    const long long kend = (gp.ksplit > 1) ? ((kbeg + gp.kchunk < gp.K) ? kbeg + gp.kchunk : gp.K) : gp.K;
+    const int NCH = (kend > kbeg) ? (int)((kend - kbeg) / RBK) : 0;
+    const int ktail = (kend > kbeg) ? (int)((kend - kbeg) % RBK) : 0;
+    const double *Ap = gp.A, *Bp = gp.B;
+    double *Cp = gp.C;
+    long long ldc = gp.ldc;
+    double alpha = gp.alpha, beta = gp.beta;
+    if (gp.ksplit > 1) { Cp = gp.ws + (size_t)blockIdx.y * gp.M * gp.N; ldc = gp.N; alpha = 1.0; beta = 0.0; }
+    const bool staged = (gp.ksplit > 1 ? (gp.N % 2 == 0) : (gp.vecC != 0)) && m0 + DBM <= M && n0 + DBN <= N;
+    const bool rdC = staged && beta != 0.0;
+    const int NG = staged ? 8 : 0, NV = NCH + NG;
+
+    doublex4 acc[4][WNI];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < WNI; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[i][j][e] = 0.0;
+
+    // ---- DMA sources of this lane (element offsets at chunk 0; every chunk adds its own k offset)
+    const long long colA_max = (M - 1) & ~1LL, colB_max = (N - 1) & ~1LL;
+    long long offA_km[2], offA_mk[2], offB[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int a = 2 * wave + u;                                  // A instruction: k-row a (k-major) / rows 16 a .. (m-major)
+        long long col = m0 + 2 * (lane ^ (8 * (a & 1)));
+        col = col < colA_max ? col : colA_max;
+        offA_km[u] = (long long)a * gp.lda + col;
+        const int r = 16 * a + (lane >> 2), c = lane & 3;
+        long long row = m0 + r;
+        row = row < M ? row : M - 1;
+        offA_mk[u] = row * gp.lda + 2 * (c ^ ((r >> 2) & 3));
+        if (WNI == 4) {
+            long long cb = n0 + 2 * (lane ^ (8 * (a & 1)));
+            cb = cb < colB_max ? cb : colB_max;
+            offB[u] = cb;                                            // + ((k0 + a) ^ kxor) ldb
+        } else {
+            const int rowb = 2 * wave + (lane >> 5);                 // one instruction: k-rows 2 wave, 2 wave + 1
+            long long cb = n0 + 2 * ((lane & 31) ^ (8 * (rowb & 1)));
+            cb = cb < colB_max ? cb : colB_max;
+            offB[u] = cb;
+        }
+    }
+    auto chunk_km = [&](long long k0) { return SYM ? (k0 >= m0 + DBM) : AKM; };
+    auto issue_ops = [&](int x) {
+        const long long k0 = kbeg + (long long)x * RBK;
+        unsigned char *sl = ring + (x & (RS - 1)) * SLOT;
+        const bool km = chunk_km(k0);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int a = 2 * wave + u;
+            const double *src = km ? Ap + k0 * gp.lda + offA_km[u] : Ap + offA_mk[u] + k0;
+            ring_dma16(src, sl + a * 1024);
+        }
+        if (WNI == 4) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int a = 2 * wave + u;
+                ring_dma16(Bp + (((k0 + a) ^ (long long)gp.kxorB)) * gp.ldb + offB[u], sl + SLOT_A + a * 1024);
+            }
+        } else {
+            const int rowb = 2 * wave + (lane >> 5);
+            ring_dma16(Bp + (((k0 + rowb) ^ (long long)gp.kxorB)) * gp.ldb + offB[0], sl + SLOT_A + wave * 1024);
+        }
+    };
+    auto issue_c = [&](int g, int slot) {                            // rows 16 g .. 16 g + 15 of the C tile -> slot
+        unsigned char *sl = ring + slot * SLOT;
+        if (WNI == 4) {
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int row = 4 * wave + rr;
+                ring_dma16(Cp + (m0 + 16 * g + row) * ldc + n0 + 2 * (lane ^ (8 * (row & 1))), sl + row * BROW);
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int row = 4 * wave + 2 * rr + (lane >> 5);
+                ring_dma16(Cp + (m0 + 16 * g + row) * ldc + n0 + 2 * ((lane & 31) ^ (8 * (row & 1))), sl + (4 * wave + 2 * rr) * BROW);
+            }
+        }
+    };
+    auto cnt = [&](int x) { return x < NCH ? NI : ((x < NV && rdC) ? NC : 0); };
+    auto issue = [&](int x) {
+        if (x < NCH) issue_ops(x);
+        else if (x < NV && rdC) issue_c(x - NCH, x & (RS - 1));
+    };
+    // products of one chunk from its slot
+    auto mfma_chunk = [&](const unsigned char *sl, bool km) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int k = 4 * ks + (lane >> 4);
+            double a[4], b[WNI];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int ml = wm * 64 + 16 * i + (lane & 15);
+                const int off = km ? k * 1024 + ((ml * 8) ^ ((k & 1) * 128)) : ml * 64 + (((k >> 1) ^ ((ml >> 2) & 3)) * 16) + (k & 1) * 8;
+                a[i] = *reinterpret_cast<const double *>(sl + off);
+            }
+#pragma unroll
+            for (int j = 0; j < WNI; j++) {
+                const int nl = wn * (16 * WNI) + 16 * j + (lane & 15);
+                b[j] = *reinterpret_cast<const double *>(sl + SLOT_A + k * BROW + ((nl * 8) ^ ((k & 1) * 128)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < WNI; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: the first three chunks are on their way before anything else happens
+    issue(0); issue(1); issue(2);
+    if (ktail > 0) {
+        // the last, partial chunk by hand into slot 3 (its rows past the end are zeros), multiplied first; chunk 3's DMA is issued behind
+        // the barrier of iteration 0, i.e. after every wave has read this
+        const long long k0 = kbeg + (long long)NCH * RBK;
+        unsigned char *sl = ring + 3 * SLOT;
+        const bool km = chunk_km(k0);
+        for (int idx = tid; idx < RBK * DBM; idx += 256) {
+            int k, ml;
+            if (km) { k = idx >> 7; ml = idx & 127; } else { ml = idx >> 3; k = idx & 7; }
+            double v = 0.0;
+            if (k < ktail && m0 + ml < M) v = km ? Ap[(k0 + k) * gp.lda + m0 + ml] : Ap[(m0 + ml) * gp.lda + k0 + k];
+            const int off = km ? k * 1024 + ((ml * 8) ^ ((k & 1) * 128)) : ml * 64 + (((k >> 1) ^ ((ml >> 2) & 3)) * 16) + (k & 1) * 8;
+            *reinterpret_cast<double *>(sl + off) = v;
+        }
+        for (int idx = tid; idx < RBK * DBN; idx += 256) {
+            const int k = idx / DBN, nl = idx % DBN;
+            double v = 0.0;
+            if (k < ktail && n0 + nl < N) v = Bp[((k0 + k) ^ (long long)gp.kxorB) * gp.ldb + n0 + nl];
+            *reinterpret_cast<double *>(sl + SLOT_A + k * BROW + ((nl * 8) ^ ((k & 1) * 128))) = v;
+        }
+        __syncthreads();          // (drains the three DMAs above: once per tile)
+        mfma_chunk(sl, km);
+    }
+    // ---- main loop: one barrier per chunk
+    for (int t = 0; t < NCH; t++) {
+        ring_wait_vm(cnt(t + 1) + cnt(t + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue(t + 3);
+        mfma_chunk(ring + (t & (RS - 1)) * SLOT, chunk_km(kbeg + (long long)t * RBK));
+    }
+    if (staged) {
+        // ---- the C tile through the ring, 16 rows per step
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const int t = NCH + g;
+            unsigned char *sl = ring + (t & (RS - 1)) * SLOT;
+            // younger than group g's DMA: the DMAs of groups g + 1, g + 2 and the stores of groups g - 3 .. g - 1
+            const int st = NC * ((g >= 3) ? 3 : g);
+            ring_wait_vm(cnt(t + 1) + cnt(t + 2) + st);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue(t + 3);
+            if (wm == (g >> 2)) {
+                double cv[WNI][4];
+#pragma unroll
+                for (int j = 0; j < WNI; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) cv[j][e] = 0.0;
+                if (rdC) {
+#pragma unroll
+                    for (int j = 0; j < WNI; j++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int rl = (lane >> 4) + 4 * e, col = wn * (16 * WNI) + 16 * j + (lane & 15);
+                            cv[j][e] = beta * *reinterpret_cast<const double *>(sl + rl * BROW + ((col * 8) ^ ((rl & 1) * 128)));
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < WNI; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int rl = (lane >> 4) + 4 * e, col = wn * (16 * WNI) + 16 * j + (lane & 15);
+                        *reinterpret_cast<double *>(sl + rl * BROW + ((col * 8) ^ ((rl & 1) * 128))) = alpha * acc[g & 3][j][e] + cv[j][e];
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS writes are done; no fence: it would drain the DMA and the stores
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (WNI == 4) {
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int row = 4 * wave + rr;
+                    const double2 v = *reinterpret_cast<const double2 *>(sl + row * BROW + ((lane * 16) ^ ((row & 1) * 128)));
+                    *reinterpret_cast<double2 *>(Cp + (m0 + 16 * g + row) * ldc + n0 + 2 * lane) = v;
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const int row = 4 * wave + 2 * rr + (lane >> 5);
+                    const double2 v = *reinterpret_cast<const double2 *>(sl + row * BROW + (((lane & 31) * 16) ^ ((row & 1) * 128)));
+                    *reinterpret_cast<double2 *>(Cp + (m0 + 16 * g + row) * ldc + n0 + 2 * (lane & 31)) = v;
+                }
+            }
+        }
+        return;
+    }
+    // ---- edge tiles: straight from the accumulators, element-wise
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < WNI; j++) {
+            const long long col = n0 + wn * (16 * WNI) + j * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const long long row = m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * e;
+                if (row < M && col < N) {
+                    double *c = Cp + row * ldc + col;
+                    double v = alpha * acc[i][j][e];
+                    if (beta != 0.0) v += beta * (*c);
+                    *c = v;
+                }
+            }
+        }
+}
+
 static __global__ void splitk_reduce_kernel(long long M, long long N, int ksplit, const double *ws, double alpha, double beta, double *C, long long ldc)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,6 +620,30 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
     }
     dim3 grid((unsigned)tiles, (unsigned)ksplit, (unsigned)d.nbatch);
     hipStream_t st = ctx->stream;
+    // LDS-DMA ring kernel: 128-row tiles, B k-major, 16-byte aligned operands, M >= 2 and N >= 2 (pairs are clamped, not masked)
+    static const bool ring_off = getenv("PG_DGEMM_RING") && atoi(getenv("PG_DGEMM_RING")) == 0;     // A/B timing and tests
+    if (!ring_off && !small_m && !d.transB && d.nbatch == 1 && gp.vecA && gp.vecB && d.M >= 2 && d.N >= 2 && d.K >= 1 && (d.kxorB % 8) == 0 &&
+        (ksplit == 1 || gp.kchunk % RBK == 0)) {
+        const long long tm_ = (d.M + 127) / 128, tn_ = (d.N + dbn - 1) / dbn;
+        const long long T = d.lower_only ? tm_ * (tm_ + 1) / 2 : tm_ * tn_;
+        dim3 rgrid((unsigned)T, (unsigned)ksplit, 1);
+        if (gp.symA) {
+            if (small_n) dgemm_ring_kernel<false, true, 2><<<rgrid, 256, 0, st>>>(gp);
+            else dgemm_ring_kernel<false, true, 4><<<rgrid, 256, 0, st>>>(gp);
+        } else if (d.transA) {
+            if (small_n) dgemm_ring_kernel<true, false, 2><<<rgrid, 256, 0, st>>>(gp);
+            else dgemm_ring_kernel<true, false, 4><<<rgrid, 256, 0, st>>>(gp);
+        } else {
+            if (small_n) dgemm_ring_kernel<false, false, 2><<<rgrid, 256, 0, st>>>(gp);
+            else dgemm_ring_kernel<false, false, 4><<<rgrid, 256, 0, st>>>(gp);
+        }
+        PG_HIP(hipGetLastError());
+        if (ksplit > 1) {
+            splitk_reduce_kernel<<<(unsigned)((d.M * d.N + 255) / 256), 256, 0, st>>>(d.M, d.N, ksplit, gp.ws, d.alpha, d.beta, d.C, d.ldc);
+            PG_HIP(hipGetLastError());
+        }
+        return PG_OK;
+    }
 #define PG_DG_LAUNCH(TA_, TB_)                                                               \
     do {                                                                                     \
         if (small_m && small_n) dgemm_kernel<TA_, TB_, 2, 2, false><<<grid, 256, 0, st>>>(gp);      \

@@ -287,16 +287,17 @@ def test_config4_one_gpu_share_n10000_c10_p125000_streamed():
     dt = time.time() - t
     pb, _ = lmm._batch_geometry(n, 0, p)
     assert st["batches"] == -(-p // pb) and st["pinned_input"] and st["bytes_in"] == n * p * 4
-    print(f"\\nconfigs[3] one-GPU share: {p} SNPs, n = {n}, c = {c}: {dt:.3f} s = {p / dt / 1e6:.3f} M SNPs/s "
+    print(f"\nconfigs[3] one-GPU share: {p} SNPs, n = {n}, c = {c}: {dt:.3f} s = {p / dt / 1e6:.3f} M SNPs/s "
           f"({st['batches']} batches of {pb}; loop {st.get('blocks_s', float('nan')):.3f} s)")
     assert len(df) == p
     for col in COLS:
         assert np.isfinite(df[col].to_numpy()).all(), col
     assert (df["p_wald"].to_numpy() <= 1).all() and (df["p_wald"].to_numpy() >= 0).all()
     seams = np.arange(pb, p, pb)
-    idx = np.unique(np.concatenate([np.arange(12), seams - 1, seams, [p - 2, p - 1], rng.integers(64, p, 64)]))[:64 + 12]
-    idx = idx[np.argsort(rng.random(idx.size))][:64]
-    idx.sort()
+    must = np.unique(np.concatenate([np.arange(12), seams - 1, seams, [p - 2, p - 1]]))
+    extra = np.setdiff1d(rng.integers(64, p, 200), must)[: max(0, 64 - must.size)]
+    idx = np.sort(np.concatenate([must, extra]))
+    assert idx.size >= 64 or must.size >= 64
     orc = O.calculate(rp["d"], rp["Y"], rp["W"], np.ascontiguousarray(X[:, idx]), grid=False, order=1, nthreads=16)
     for col in COLS[:5]:
         assert (bits(df[col].to_numpy()[idx]) == bits(orc[col].astype(df[col].dtype))).all(), col

@@ -40,6 +40,76 @@ def test_dgemm_mfma_f64(ta, M, N, K, ctx):
     assert np.abs(got - ref).max() <= 1e-12 * np.sqrt(K) * 10
 
 
+TA, TB, LOW, SYM, NOSPLIT = 1, 2, 4, 8, 16
+
+
+def _dgemm_ex(ctx, flags, kxor, M, N, K, alpha, A, lda, B, ldb, beta, Cm, ldc):
+    from pygemma_amd import _lib
+    L = _lib.load()
+    dA, dB, dC = ctx.to_device(A), ctx.to_device(B), ctx.to_device(Cm)
+    _lib.check(L.pgx_dgemm_ex_dev(ctx.handle, flags, kxor, M, N, K, alpha, dA.ptr, lda, dB.ptr, ldb, beta, dC.ptr, ldc), "dgemm_ex")
+    ctx.sync()
+    out = dC.download(Cm.shape, np.float64)
+    for b_ in (dA, dB, dC):
+        b_.free()
+    return out
+
+
+@pytest.mark.parametrize("ta", [0, 1])
+@pytest.mark.parametrize("beta", [0.0, 0.5])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 8), (256, 128, 24), (200, 130, 77), (513, 260, 128), (300, 64, 1000), (1000, 1000, 256),
+                                   (129, 64, 2051), (640, 192, 3), (2, 2, 5), (4000, 64, 64), (1280, 1280, 39)])
+def test_dgemm_ring_kernel_shapes(ta, beta, M, N, K, ctx):
+    """The LDS-DMA ring kernel (csrc/dgemm.hpp) on full tiles, ragged edges in M and N, K tails (K % 8 != 0), K shorter than the ring,
+    64-wide outputs, with and without the C tile read back (beta), both A layouts, with sub-matrix strides; against NumPy fp64."""
+    rng = np.random.default_rng(1000 * M + 10 * N + K + ta)
+    lda = ((M if ta else K) + 7) // 2 * 2          # even: 16-byte rows (the ring kernel's precondition; odd strides take the register-staged kernel)
+    ldb, ldc = N + 2, N + 4
+    A = rng.standard_normal((K if ta else M, lda))
+    B = rng.standard_normal((K, ldb))
+    Cm = rng.standard_normal((M, ldc))
+    got = _dgemm_ex(ctx, TA if ta else 0, 0, M, N, K, -1.5, A, lda, B, ldb, beta, Cm, ldc)
+    Aop = A[:, :M].T if ta else A[:, :K]
+    ref = Cm.copy()
+    ref[:, :N] = -1.5 * (Aop @ B[:, :N]) + beta * Cm[:, :N]
+    assert np.abs(got - ref).max() <= 1e-12 * np.sqrt(K) * 10
+    assert (got[:, N:] == Cm[:, N:]).all()
+
+
+@pytest.mark.parametrize("m,pad", [(640, 0), (1000, 64), (2304, 0), (130, 0)])
+def test_dgemm_rank_2b_update_on_the_lower_triangle(m, pad, ctx):
+    """The band reduction's update A22 -= [V W][W V]' as it is called (csrc/sb2.hip): both operands the SAME k-major array [V W]'
+    (128 x ldt), the second read with its k index XOR-ed by 64, lower triangle of C only (tiles above the diagonal untouched)."""
+    rng = np.random.default_rng(m)
+    mm = m + pad
+    ldt = (mm + 255) // 128 * 128
+    VWt = np.zeros((128, ldt))
+    VWt[:, pad:mm] = rng.standard_normal((128, m))
+    Cm = rng.standard_normal((mm, mm + 2))
+    got = _dgemm_ex(ctx, TA | LOW, 64, mm, mm, 128, -1.0, VWt, ldt, VWt, ldt, 1.0, Cm, mm + 2)
+    V, W = VWt[:64, :mm].T, VWt[64:, :mm].T
+    ref = Cm[:, :mm] - (V @ W.T + W @ V.T)
+    i, j = np.indices((mm, mm))
+    low = (j // 128) <= (i // 128)                       # tiles on or below the diagonal
+    assert np.abs(got[:, :mm] - ref)[low].max() <= 1e-12
+    assert (got[:, :mm][~low] == Cm[:, :mm][~low]).all()
+
+
+@pytest.mark.parametrize("m,N,split", [(640, 64, 0), (1000, 64, 0), (2304, 64, 1), (2304, 64, 0), (777, 128, 0), (1290, 192, 1)])
+def test_dgemm_symmetric_A_from_its_lower_triangle(m, N, split, ctx):
+    """X = A V with A symmetric and only its lower triangle + the full 128 x 128 diagonal tiles valid (the rest is NaN here and must never
+    be read): k-chunks left of / on the diagonal tile m-major, right of it k-major from the transposed position; with and without split K."""
+    rng = np.random.default_rng(m + N)
+    S = rng.standard_normal((m, m)); S = S + S.T
+    i, j = np.indices((m, m))
+    A = np.where((j // 128) <= (i // 128), S, np.nan)
+    V = rng.standard_normal((m, N + 2))
+    Cm = np.zeros((m, N))
+    got = _dgemm_ex(ctx, SYM | (0 if split else NOSPLIT), 0, m, N, m, 1.0, A, m, V, N + 2, 0.0, Cm, N)
+    assert np.isfinite(got).all()
+    assert np.abs(got - S @ V[:, :N]).max() <= 1e-12 * np.sqrt(m) * 10
+
+
 @pytest.mark.parametrize("n", [5, 64, 65, 130, 300, 777])
 def test_sytrd_similarity(n, ctx):
     """T = Q' K Q: the tridiagonal's eigenvalues equal K's (fp64), and Q built from the reflectors is
