@@ -279,6 +279,8 @@ int pgx_dgemm_dev(pg_ctx *ctx, int transA, int64_t M, int64_t N, int64_t K, doub
  * bit 3 A symmetric (lower triangle + full diagonal tiles valid), bit 4 no split-K; kxorB: B's k index XOR-ed (multiple of 8) */
 int pgx_dgemm_ex_dev(pg_ctx *ctx, int flags, int kxorB, int64_t M, int64_t N, int64_t K, double alpha, const double *A, int64_t lda,
                      const double *B, int64_t ldb, double beta, double *C, int64_t ldc);
+/* pgx_ring_stamps: in-kernel time stamps one workgroup of the ring GEMM left when PG_DGEMM_TUNE has bit 3 set (diagnostics) */
+int pgx_ring_stamps(long long *out64);
 int pgx_sytrd_dev(pg_ctx *ctx, int64_t n, const float *K, double *d, double *e, double *tau, double *Vall);
 int pgx_stedc_dev(pg_ctx *ctx, int64_t n, const double *d_host, const double *e_host, double *evals_host, double *Z_dev);
 /* The two-stage tridiagonalisation of pg_syevd_dev (csrc/sb2.hip), one stage at a time (all matrices n x n fp64 row-major on the device):

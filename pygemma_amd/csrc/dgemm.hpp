@@ -19,6 +19,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 namespace pg {
@@ -47,6 +48,8 @@ struct DgemmParams {
     long long M_last, K_last;               // dimensions of batch element nbatch - 1 (0: same as M / K)
     int symA;                               // TA = false only; needs 128-row tiles (WMI = 4) and lda = row stride of the symmetric matrix
     int vecC;                               // C base, ldc and strideC allow 16-byte accesses
+    long long *stamps;                      // diagnostics: in-kernel time stamps of one workgroup (nullptr: none)
+    int tune;                               // ring kernel experiments (PG_DGEMM_TUNE): bit 0 s_setprio around the products, bit 1 start-up stagger
 };
 
 template <bool TA, bool TB, int WMI, int WNI, bool SYM>
@@ -300,7 +303,17 @@ __device__ __forceinline__ void ring_wait_vm(int n)
         case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
         case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
         case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+        case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+        case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+        case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
     }
 }
 __device__ __forceinline__ void ring_dma16(const double *src, unsigned char *dst)
@@ -308,15 +321,31 @@ __device__ __forceinline__ void ring_dma16(const double *src, unsigned char *dst
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
 }
 
+// in-kernel time stamps of ONE workgroup (PG_DGEMM_TUNE bit 3; blockIdx.x == 300): where a tile's time goes — diagnostics only
+extern long long *g_ring_stamp_buf;      // device buffer of 64 stamps (syevd.hip: pgx_ring_stamps), nullptr until asked for
+#define RING_STAMP(ix) do { if (stamp) gp.stamps[ix] = __builtin_amdgcn_s_memtime(); } while (0)
+
 template <bool AKM, bool SYM, int WNI>
 __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
 {
+    const bool stamp = gp.stamps != nullptr && blockIdx.x == 300 && blockIdx.y == 0 && threadIdx.x == 0;
+    RING_STAMP(0);
+    // Two workgroups share a CU, one wave of each per SIMD.  With equal priority the SIMD's arbiter alternates between their MFMAs, both
+    // finish a chunk's 32 products together and then do their per-chunk overhead (waits, barrier, DMA issue: ~1 500 cycles) together —
+    // the matrix pipe idles meanwhile (5 600 cycles per chunk where 4 096 are products: in-kernel stamps, r4).  Unequal priorities break the
+    // symmetry: the wave in the odd wave slot of its SIMD always wins, runs as if alone, and the other one fills every gap it leaves.
+    if (!(gp.tune & 64)) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));    // HW_REG_HW_ID, bits 3:0 = wave slot in the SIMD
+        if (hw & 1) __builtin_amdgcn_s_setprio(2);
+    }
     constexpr int DBM = 128, DBN = 32 * WNI;
     constexpr int BROW = DBN * 8;                       // bytes of one k-row of the B image (and of one row of a staged C group)
     constexpr int SLOT_A = 8192, SLOT = SLOT_A + RBK * BROW;
     constexpr int NI = (WNI == 4) ? 4 : 3;              // DMA instructions per wave and operand chunk
     constexpr int NC = (WNI == 4) ? 4 : 2;              // ... per staged C group, and global stores per wave and group
-    __shared__ __attribute__((aligned(1024))) unsigned char ring[RS * SLOT];
+    // dynamic: RS slots + 4 KB that nothing reads (the landing area of the C prefetch below); above 64 KB only dynamic LDS is honoured
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+    unsigned char *const dummy = ring + RS * SLOT;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const long long M = gp.M, N = gp.N;
@@ -419,6 +448,21 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
             }
         }
     };
+    // C prefetch: the tile's 128 KB cannot wait in LDS, but it can wait in L2 / the memory-side cache.  During the last 16 chunks every
+    // wave touches two rows of the tile per chunk with an LDS-DMA whose LDS side nobody reads; the real DMA of the row groups then finds
+    // the lines on chip (without this the 8 short epilogue steps each waited a loaded HBM round trip: 27 of a tile's 103 kilocycles).
+    const bool pfC = rdC && WNI == 4 && (gp.tune & 4);     // measured: no gain (r4 call 5) — off unless PG_DGEMM_TUNE bit 2
+    const int pf_start = (NCH > 16) ? NCH - 16 : 0;
+    auto PF = [&](int t) { return (pfC && t >= pf_start && t < NCH && t >= 0) ? 2 : 0; };
+    auto prefetch = [&](int t) {
+        if (PF(t) == 0) return;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            int row = (t - pf_start) * 8 + 2 * wave + u;
+            row = row < DBM ? row : DBM - 1;
+            ring_dma16(Cp + (m0 + row) * ldc + n0 + 2 * lane, dummy + wave * 1024);
+        }
+    };
     auto cnt = [&](int x) { return x < NCH ? NI : ((x < NV && rdC) ? NC : 0); };
     auto issue = [&](int x) {
         if (x < NCH) issue_ops(x);
@@ -450,6 +494,14 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
 
     // ---- prologue: the first three chunks are on their way before anything else happens
     issue(0); issue(1); issue(2);
+    RING_STAMP(1);
+    if ((gp.tune & 2) && (((gp.tune & 16) ? (blockIdx.x >> 3) : (blockIdx.x >> 8)) & 1)) {
+        // the two workgroups of a CU start together and take equally long: without this they stay in phase — both in their products, then
+        // both in their epilogues, the matrix pipe idle meanwhile.  The workgroups of the second dispatch round per CU start half a tile late.
+        const long long t0 = wall_clock64();
+        const long long hold = (long long)(gp.tune >> 8) * 100;   // microseconds in bits 8.. of PG_DGEMM_TUNE -> 100 MHz ticks
+        while (wall_clock64() - t0 < hold) __builtin_amdgcn_s_sleep(8);
+    }
     if (ktail > 0) {
         // the last, partial chunk by hand into slot 3 (its rows past the end are zeros), multiplied first; chunk 3's DMA is issued behind
         // the barrier of iteration 0, i.e. after every wave has read this
@@ -474,14 +526,33 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
         mfma_chunk(sl, km);
     }
     // ---- main loop: one barrier per chunk
+    const bool pf_any = pfC;
     for (int t = 0; t < NCH; t++) {
-        ring_wait_vm(cnt(t + 1) + cnt(t + 2));
+        if (t == 8) RING_STAMP(32);
+        // steady state (two operand chunks younger than the one waited for, no prefetch in flight): an immediate — the computed count
+        // below is a 30-way compare chain of ~400 cycles, paid per chunk
+        if (t + 2 < NCH && !pf_any) {
+            if (NI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else ring_wait_vm(PF(t - 3) + cnt(t + 1) + PF(t - 2) + cnt(t + 2) + PF(t - 1));
+        if (t == 8) RING_STAMP(33);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (t == 0) RING_STAMP(2);
+        if (t == 1) RING_STAMP(3);
+        if (t == 8) RING_STAMP(4);
         issue(t + 3);
+        if (t == 8) RING_STAMP(34);
+        prefetch(t);
+        if (t == 8) RING_STAMP(35);
+        if (gp.tune & 1) __builtin_amdgcn_s_setprio(1);
         mfma_chunk(ring + (t & (RS - 1)) * SLOT, chunk_km(kbeg + (long long)t * RBK));
+        if (gp.tune & 1) __builtin_amdgcn_s_setprio(0);
+        if (t == 8) RING_STAMP(36);
+        if (t == 9) RING_STAMP(37);
     }
+    RING_STAMP(5);
     if (staged) {
         // ---- the C tile through the ring, 16 rows per step
 #pragma unroll
@@ -490,10 +561,11 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
             unsigned char *sl = ring + (t & (RS - 1)) * SLOT;
             // younger than group g's DMA: the DMAs of groups g + 1, g + 2 and the stores of groups g - 3 .. g - 1
             const int st = NC * ((g >= 3) ? 3 : g);
-            ring_wait_vm(cnt(t + 1) + cnt(t + 2) + st);
+            ring_wait_vm(cnt(t + 1) + cnt(t + 2) + st + PF(t - 3) + PF(t - 2) + PF(t - 1));
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            RING_STAMP(8 + 2 * g);
             issue(t + 3);
             if (wm == (g >> 2)) {
                 double cv[WNI][4];
@@ -537,7 +609,10 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
                     *reinterpret_cast<double2 *>(Cp + (m0 + 16 * g + row) * ldc + n0 + 2 * (lane & 31)) = v;
                 }
             }
+            RING_STAMP(9 + 2 * g);
         }
+        RING_STAMP(6);
+        if (stamp) gp.stamps[7] = __builtin_amdgcn_s_memrealtime();
         return;
     }
     // ---- edge tiles: straight from the accumulators, element-wise
@@ -600,6 +675,9 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
     gp.vecB = ((uintptr_t)d.B % 16 == 0) && (d.ldb % 2 == 0) && (d.strideB % 2 == 0);
     gp.symA = (d.symA && !d.transA) ? 1 : 0;
     gp.vecC = ((uintptr_t)d.C % 16 == 0) && (d.ldc % 2 == 0) && (d.strideC % 2 == 0);
+    static const int tune_env = getenv("PG_DGEMM_TUNE") ? atoi(getenv("PG_DGEMM_TUNE")) : 0;
+    gp.tune = tune_env;
+    gp.stamps = (tune_env & 8) ? g_ring_stamp_buf : nullptr;
     const bool small_m = d.M <= 64 && !d.symA, small_n = d.N <= 64 && !d.lower_only;
     const int dbm = small_m ? 64 : 128, dbn = small_n ? 64 : 128;
     const long long tiles = ((d.M + dbm - 1) / dbm) * ((d.N + dbn - 1) / dbn);
@@ -609,6 +687,19 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
         // at least 128 k per slice (a 64 x 64 Gram of 7400 rows: 28 slices of 264 k 26 us, 57 of 128 k 17 us; 64 k no better, 32 worse)
         ksplit = (int)std::min<long long>((768 + tiles - 1) / tiles, d.K / 128);
         if (ksplit < 2) ksplit = 1;
+        static const int ks_mode = getenv("PG_DGEMM_KSPLIT_FILL") ? atoi(getenv("PG_DGEMM_KSPLIT_FILL")) : 1;
+        if (ks_mode && tiles >= 16) {
+            // long-K shapes with many row tiles (X = A22 V): two workgroups per CU are resident, so tiles x slices should fill whole
+            // rounds of 2 x CUs workgroups; among the slice counts with >= 256 k each take the best fill, the fewest slices at a tie
+            const long long slots = 2LL * ctx->num_cu;
+            double best = -1.0; int best_ks = 1;
+            for (int ks = 1; ks <= 16 && d.K / ks >= 256; ks++) {
+                const long long wg = tiles * ks, rounds = (wg + slots - 1) / slots;
+                const double fill = (double)wg / (double)(rounds * slots);
+                if (fill > best + 0.03) { best = fill; best_ks = ks; }
+            }
+            ksplit = best_ks;
+        }
     }
     if (ksplit > 1) {
         long long kchunk = (d.K + ksplit - 1) / ksplit;
@@ -627,15 +718,32 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
         const long long tm_ = (d.M + 127) / 128, tn_ = (d.N + dbn - 1) / dbn;
         const long long T = d.lower_only ? tm_ * (tm_ + 1) / 2 : tm_ * tn_;
         dim3 rgrid((unsigned)T, (unsigned)ksplit, 1);
+        constexpr int LDS4 = RS * (8192 + RBK * 1024) + 4096, LDS2 = RS * (8192 + RBK * 512) + 4096;
+        {   // the 128-wide variants take 68 KB of dynamic LDS: a per-DEVICE function attribute, set on a device's first call
+            static std::atomic<unsigned> done_mask{0};
+            const unsigned bit = 1u << (ctx->device & 31);
+            if (!(done_mask.load(std::memory_order_acquire) & bit)) {
+                PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dgemm_ring_kernel<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+                PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dgemm_ring_kernel<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+                PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dgemm_ring_kernel<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+                done_mask.fetch_or(bit, std::memory_order_release);
+            }
+        }
+        const int xl = (gp.tune & 32) ? 40960 : 0;      // diagnostics: + 40 KB, so that one workgroup per CU is resident
+        if (xl) {
+            PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dgemm_ring_kernel<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4 + xl));
+            PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dgemm_ring_kernel<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4 + xl));
+            PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dgemm_ring_kernel<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4 + xl));
+        }
         if (gp.symA) {
-            if (small_n) dgemm_ring_kernel<false, true, 2><<<rgrid, 256, 0, st>>>(gp);
-            else dgemm_ring_kernel<false, true, 4><<<rgrid, 256, 0, st>>>(gp);
+            if (small_n) dgemm_ring_kernel<false, true, 2><<<rgrid, 256, LDS2, st>>>(gp);
+            else dgemm_ring_kernel<false, true, 4><<<rgrid, 256, LDS4 + xl, st>>>(gp);
         } else if (d.transA) {
-            if (small_n) dgemm_ring_kernel<true, false, 2><<<rgrid, 256, 0, st>>>(gp);
-            else dgemm_ring_kernel<true, false, 4><<<rgrid, 256, 0, st>>>(gp);
+            if (small_n) dgemm_ring_kernel<true, false, 2><<<rgrid, 256, LDS2, st>>>(gp);
+            else dgemm_ring_kernel<true, false, 4><<<rgrid, 256, LDS4 + xl, st>>>(gp);
         } else {
-            if (small_n) dgemm_ring_kernel<false, false, 2><<<rgrid, 256, 0, st>>>(gp);
-            else dgemm_ring_kernel<false, false, 4><<<rgrid, 256, 0, st>>>(gp);
+            if (small_n) dgemm_ring_kernel<false, false, 2><<<rgrid, 256, LDS2, st>>>(gp);
+            else dgemm_ring_kernel<false, false, 4><<<rgrid, 256, LDS4 + xl, st>>>(gp);
         }
         PG_HIP(hipGetLastError());
         if (ksplit > 1) {

@@ -1057,6 +1057,20 @@ extern "C" int pgx_dgemm_ex_dev(pg_ctx *ctx, int flags, int kxorB, int64_t M, in
     return dgemm_ex(ctx, d);
 }
 
+// the time stamps one workgroup of the ring GEMM left (PG_DGEMM_TUNE bit 3): 64 values, see RING_STAMP in dgemm.hpp
+namespace pg { long long *g_ring_stamp_buf = nullptr; }
+extern "C" int pgx_ring_stamps(long long *out64)
+{
+    PG_REQUIRE(out64, "pgx_ring_stamps: NULL argument");
+    if (!pg::g_ring_stamp_buf) {            // first call: make the buffer; the GEMMs launched from now on (with PG_DGEMM_TUNE bit 3) fill it
+        PG_HIP(hipMalloc(reinterpret_cast<void **>(&pg::g_ring_stamp_buf), 64 * sizeof(long long)));
+        PG_HIP(hipMemset(pg::g_ring_stamp_buf, 0, 64 * sizeof(long long)));
+    }
+    PG_HIP(hipDeviceSynchronize());
+    PG_HIP(hipMemcpy(out64, pg::g_ring_stamp_buf, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    return PG_OK;
+}
+
 // ---- lmm/lmm.py:124-125  K <- Z K Z'  (Z: n x q, K: q x q; float32 or float64 each) on the device ----------------------------------
 // Two fp64-MFMA products, T = Z K and R = T Z', and ONE rounding to float32 at the end (the reference rounds once per float32 BLAS
 // product when both inputs are float32, or once at lmm.py:127-128 when one is float64: either way the result below is within one

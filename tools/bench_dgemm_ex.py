@@ -5,11 +5,14 @@ import numpy as np
 sys.path.insert(0, '/root/repo')
 from pygemma_amd import _lib
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+only = sys.argv[2] if len(sys.argv) > 2 else ""      # substring filter on the shape name
 L = _lib.load(); ctx = _lib.Context(0)
 rng = np.random.default_rng(0)
 TA, TB, LOW, SYM, NOSPLIT = 1, 2, 4, 8, 16
 
 def bench(name, flags, kxor, M, N, K, beta, lda, ldb, ldc, a_shape, b_shape, c_shape, flops):
+    if only and only not in name:
+        return
     dA = ctx.to_device(rng.standard_normal(a_shape)); dB = dA if b_shape is None else ctx.to_device(rng.standard_normal(b_shape))
     dC = ctx.to_device(np.zeros(c_shape))
     def run():
