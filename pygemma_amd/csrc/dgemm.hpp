@@ -322,6 +322,7 @@ __device__ __forceinline__ void ring_dma16(const double *src, unsigned char *dst
 }
 
 // in-kernel time stamps of ONE workgroup (PG_DGEMM_TUNE bit 3; blockIdx.x == 300): where a tile's time goes — diagnostics only
+static __device__ int g_cu_ticket[2048];      // arrivals per physical CU (start-up stagger experiment, PG_DGEMM_TUNE bit 1)
 extern long long *g_ring_stamp_buf;      // device buffer of 64 stamps (syevd.hip: pgx_ring_stamps), nullptr until asked for
 #define RING_STAMP(ix) do { if (stamp) gp.stamps[ix] = __builtin_amdgcn_s_memtime(); } while (0)
 
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
     // finish a chunk's 32 products together and then do their per-chunk overhead (waits, barrier, DMA issue: ~1 500 cycles) together —
     // the matrix pipe idles meanwhile (5 600 cycles per chunk where 4 096 are products: in-kernel stamps, r4).  Unequal priorities break the
     // symmetry: the wave in the odd wave slot of its SIMD always wins, runs as if alone, and the other one fills every gap it leaves.
-    if (!(gp.tune & 64)) {
+    if (gp.tune & 64) {       // measured: no effect on any shape (r4) — kept as an experiment switch
         const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));    // HW_REG_HW_ID, bits 3:0 = wave slot in the SIMD
         if (hw & 1) __builtin_amdgcn_s_setprio(2);
     }
@@ -352,12 +353,12 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
     // tile of this workgroup: XCD-contiguous remap of the launch index (workgroups b and b + 8 share an XCD's L2), then row-major —
     // or, for a symmetric update, the enumeration of the lower triangle
     const int tiles_m = (int)((M + DBM - 1) / DBM), tiles_n = (int)((N + DBN - 1) / DBN);
-    const int T = gp.lower ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+    const int T = (gp.lower == 1) ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
     int tm, tn;
     {
         const int b = blockIdx.x, q = T / 8, r = T % 8, xcd = b % 8;
         const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-        if (gp.lower) {
+        if (gp.lower == 1) {
             int t_ = (int)((sqrt(8.0 * (double)lid + 1.0) - 1.0) * 0.5);
             while ((t_ + 1) * (t_ + 2) / 2 <= lid) t_++;
             while (t_ * (t_ + 1) / 2 > lid) t_--;
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
         } else { tm = lid / tiles_n; tn = lid % tiles_n; }
     }
     const long long m0 = (long long)tm * DBM, n0 = (long long)tn * DBN;
+    if (gp.lower == 2 && n0 >= m0 + DBM) return;          // uniform over the workgroup, before any barrier
     const long long kbeg = (gp.ksplit > 1) ? (long long)blockIdx.y * gp.kchunk : 0;
     const long long kend = (gp.ksplit > 1) ? ((kbeg + gp.kchunk < gp.K) ? kbeg + gp.kchunk : gp.K) : gp.K;
     const int NCH = (kend > kbeg) ? (int)((kend - kbeg) / RBK) : 0;
@@ -463,39 +465,93 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
             ring_dma16(Cp + (m0 + row) * ldc + n0 + 2 * lane, dummy + wave * 1024);
         }
     };
+    // one DMA instruction of virtual chunk x (operand chunk: A piece 0, 1, then B; C group: its rows): issued BETWEEN the products of the
+    // chunk being multiplied — an MFMA holds the wave's issue port for 8 of its 64 cycles, so a DMA's ~120 issue cycles disappear in the
+    // shadow of the products; issued in one block before them they were 480 of a chunk's 3 200 cycles (in-kernel stamps, r4)
+    auto issue_piece = [&](int x, int piece) {
+        if (x < NCH) {
+            const long long k0 = kbeg + (long long)x * RBK;
+            unsigned char *sl = ring + (x & (RS - 1)) * SLOT;
+            if (piece < 2) {
+                const bool km = chunk_km(k0);
+                const int a = 2 * wave + piece;
+                const double *src = km ? Ap + k0 * gp.lda + offA_km[piece] : Ap + offA_mk[piece] + k0;
+                ring_dma16(src, sl + a * 1024);
+            } else if (WNI == 4) {
+                const int a = 2 * wave + (piece - 2);
+                ring_dma16(Bp + (((k0 + a) ^ (long long)gp.kxorB)) * gp.ldb + offB[piece - 2], sl + SLOT_A + a * 1024);
+            } else if (piece == 2) {
+                const int rowb = 2 * wave + (lane >> 5);
+                ring_dma16(Bp + (((k0 + rowb) ^ (long long)gp.kxorB)) * gp.ldb + offB[0], sl + SLOT_A + wave * 1024);
+            }
+        } else if (x < NV && rdC) {
+            const int g = x - NCH;
+            unsigned char *sl = ring + (x & (RS - 1)) * SLOT;
+            if (WNI == 4) {
+                const int row = 4 * wave + piece;
+                ring_dma16(Cp + (m0 + 16 * g + row) * ldc + n0 + 2 * (lane ^ (8 * (row & 1))), sl + row * BROW);
+            } else if (piece < 2) {
+                const int row = 4 * wave + 2 * piece + (lane >> 5);
+                ring_dma16(Cp + (m0 + 16 * g + row) * ldc + n0 + 2 * ((lane & 31) ^ (8 * (row & 1))), sl + (4 * wave + 2 * piece) * BROW);
+            }
+        }
+    };
     auto cnt = [&](int x) { return x < NCH ? NI : ((x < NV && rdC) ? NC : 0); };
     auto issue = [&](int x) {
         if (x < NCH) issue_ops(x);
         else if (x < NV && rdC) issue_c(x - NCH, x & (RS - 1));
     };
     // products of one chunk from its slot
-    auto mfma_chunk = [&](const unsigned char *sl, bool km) {
+    auto frag_a = [&](const unsigned char *sl, bool km, int ks, int i) {
+        const int k = 4 * ks + (lane >> 4), ml = wm * 64 + 16 * i + (lane & 15);
+        const int off = km ? k * 1024 + ((ml * 8) ^ ((k & 1) * 128)) : ml * 64 + (((k >> 1) ^ ((ml >> 2) & 3)) * 16) + (k & 1) * 8;
+        return *reinterpret_cast<const double *>(sl + off);
+    };
+    auto frag_b = [&](const unsigned char *sl, int ks, int j) {
+        const int k = 4 * ks + (lane >> 4), nl = wn * (16 * WNI) + 16 * j + (lane & 15);
+        return *reinterpret_cast<const double *>(sl + SLOT_A + k * BROW + ((nl * 8) ^ ((k & 1) * 128)));
+    };
+    // the 32 (16) products of one chunk from its slot; xi >= 0: the DMA instructions of virtual chunk xi go out between them
+    auto mfma_chunk = [&](const unsigned char *sl, bool km, int xi) {
+        double a0[4], b0[WNI], a1[4], b1[WNI];
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            const int k = 4 * ks + (lane >> 4);
-            double a[4], b[WNI];
+        for (int i = 0; i < 4; i++) a0[i] = frag_a(sl, km, 0, i);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int ml = wm * 64 + 16 * i + (lane & 15);
-                const int off = km ? k * 1024 + ((ml * 8) ^ ((k & 1) * 128)) : ml * 64 + (((k >> 1) ^ ((ml >> 2) & 3)) * 16) + (k & 1) * 8;
-                a[i] = *reinterpret_cast<const double *>(sl + off);
+        for (int j = 0; j < WNI; j++) b0[j] = frag_b(sl, 0, j);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = 0; j < WNI; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (xi >= 0) issue_piece(xi, i);
+            if (i == 1) {      // the second k-step's fragments: in flight under the remaining products of the first
+#pragma unroll
+                for (int i2 = 0; i2 < 4; i2++) a1[i2] = frag_a(sl, km, 1, i2);
+#pragma unroll
+                for (int j = 0; j < WNI; j++) b1[j] = frag_b(sl, 1, j);
             }
-#pragma unroll
-            for (int j = 0; j < WNI; j++) {
-                const int nl = wn * (16 * WNI) + 16 * j + (lane & 15);
-                b[j] = *reinterpret_cast<const double *>(sl + SLOT_A + k * BROW + ((nl * 8) ^ ((k & 1) * 128)));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < WNI; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < WNI; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
     };
 
     // ---- prologue: the first three chunks are on their way before anything else happens
     issue(0); issue(1); issue(2);
     RING_STAMP(1);
-    if ((gp.tune & 2) && (((gp.tune & 16) ? (blockIdx.x >> 3) : (blockIdx.x >> 8)) & 1)) {
+    bool hold_me = false;
+    if ((gp.tune & 2) && blockIdx.x < 2 * 256) {
+        // first-round workgroups take a ticket on their physical CU (XCC, SE, SH, CU from the hardware id registers): the second to arrive waits
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (8 << 6) | ((8 - 1) << 11));       // HW_ID bits 15:8: CU_ID, SH_ID, SE_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11));     // XCC_ID bits 3:0
+        __shared__ int tk_sh;
+        if (threadIdx.x == 0) tk_sh = atomicAdd(&g_cu_ticket[((xcc & 7) << 8) | (hw & 255)], 1);
+        __syncthreads();
+        hold_me = (tk_sh & 1) != 0;
+    }
+    if (hold_me) {
         // the two workgroups of a CU start together and take equally long: without this they stay in phase — both in their products, then
         // both in their epilogues, the matrix pipe idle meanwhile.  The workgroups of the second dispatch round per CU start half a tile late.
         const long long t0 = wall_clock64();
@@ -523,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
             *reinterpret_cast<double *>(sl + SLOT_A + k * BROW + ((nl * 8) ^ ((k & 1) * 128))) = v;
         }
         __syncthreads();          // (drains the three DMAs above: once per tile)
-        mfma_chunk(sl, km);
+        mfma_chunk(sl, km, -1);
     }
     // ---- main loop: one barrier per chunk
     const bool pf_any = pfC;
@@ -542,13 +598,11 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
         if (t == 0) RING_STAMP(2);
         if (t == 1) RING_STAMP(3);
         if (t == 8) RING_STAMP(4);
-        issue(t + 3);
+        if (gp.tune & 128) issue(t + 3);          // A/B: the DMA in one block before the products (as until r4 call 9)
         if (t == 8) RING_STAMP(34);
         prefetch(t);
         if (t == 8) RING_STAMP(35);
-        if (gp.tune & 1) __builtin_amdgcn_s_setprio(1);
-        mfma_chunk(ring + (t & (RS - 1)) * SLOT, chunk_km(kbeg + (long long)t * RBK));
-        if (gp.tune & 1) __builtin_amdgcn_s_setprio(0);
+        mfma_chunk(ring + (t & (RS - 1)) * SLOT, chunk_km(kbeg + (long long)t * RBK), (gp.tune & 128) ? -1 : t + 3);
         if (t == 8) RING_STAMP(36);
         if (t == 9) RING_STAMP(37);
     }
@@ -660,6 +714,9 @@ struct DgemmDesc {
     long long strideA = 0, strideB = 0, strideC = 0, M_last = 0, K_last = 0;
     bool allow_splitk = true;
     bool symA = false;
+    // split-K products whose caller sums the slices itself (fused with what follows): no reduction kernel is launched;
+    // *partials receives {slices, slab base (slice z at base + z M N, row-major M x N)} — slices == 1: the product went to C as usual
+    struct Partials { int slices = 1; const double *ws = nullptr; } *partials = nullptr;
 };
 
 inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
@@ -716,7 +773,11 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
     if (!ring_off && !small_m && !d.transB && d.nbatch == 1 && gp.vecA && gp.vecB && d.M >= 2 && d.N >= 2 && d.K >= 1 && (d.kxorB % 8) == 0 &&
         (ksplit == 1 || gp.kchunk % RBK == 0)) {
         const long long tm_ = (d.M + 127) / 128, tn_ = (d.N + dbn - 1) / dbn;
-        const long long T = d.lower_only ? tm_ * (tm_ + 1) / 2 : tm_ * tn_;
+        // lower triangle of a square C: the triangle's tiles are enumerated; of a rectangular one (a tile column of an update): every
+        // tile of the rectangle is launched and those above the diagonal leave at once (gp.lower == 2)
+        const bool tri = d.lower_only && tm_ == tn_ && dbn == 128;
+        gp.lower = tri ? 1 : (d.lower_only ? 2 : 0);
+        const long long T = tri ? tm_ * (tm_ + 1) / 2 : tm_ * tn_;
         dim3 rgrid((unsigned)T, (unsigned)ksplit, 1);
         constexpr int LDS4 = RS * (8192 + RBK * 1024) + 4096, LDS2 = RS * (8192 + RBK * 512) + 4096;
         {   // the 128-wide variants take 68 KB of dynamic LDS: a per-DEVICE function attribute, set on a device's first call
@@ -746,7 +807,8 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
             else dgemm_ring_kernel<false, false, 4><<<rgrid, 256, LDS4 + xl, st>>>(gp);
         }
         PG_HIP(hipGetLastError());
-        if (ksplit > 1) {
+        if (d.partials) { d.partials->slices = ksplit; d.partials->ws = (ksplit > 1) ? gp.ws : nullptr; }
+        if (ksplit > 1 && !d.partials) {
             splitk_reduce_kernel<<<(unsigned)((d.M * d.N + 255) / 256), 256, 0, st>>>(d.M, d.N, ksplit, gp.ws, d.alpha, d.beta, d.C, d.ldc);
             PG_HIP(hipGetLastError());
         }
@@ -768,7 +830,8 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
     else PG_DG_LAUNCH(false, false);
 #undef PG_DG_LAUNCH
     PG_HIP(hipGetLastError());
-    if (ksplit > 1) {
+    if (d.partials) { d.partials->slices = ksplit; d.partials->ws = (ksplit > 1) ? gp.ws : nullptr; }
+    if (ksplit > 1 && !d.partials) {
         splitk_reduce_kernel<<<(unsigned)((d.M * d.N + 255) / 256), 256, 0, st>>>(d.M, d.N, ksplit, gp.ws, d.alpha, d.beta, d.C, d.ldc);
         PG_HIP(hipGetLastError());
     }

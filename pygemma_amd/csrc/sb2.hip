@@ -492,13 +492,302 @@ __global__ void copy_v_kernel(long long m, long long r_begin, const double *VW, 
     if (r < m) Vst[r * ldv + c] = VW[r * (2 * B) + c];
 }
 
+// ---- fused panel kernels (r4): the chain of thin products between the two big GEMMs of a panel ------------------------------------
+// Until r4 every thin product of a panel (P R1^-1, Q1'Q1, Q1 Xm, X T, V'Y, T'M1, Y + V M2) was its own dgemm launch of 10 - 17 us —
+// a 128-row tile kernel walking K = 64 with one barrier per 8 k — plus split-K reductions, a copy and a transposition: 12 launches
+// and ~150 us per panel beside the two big GEMMs.  Here each step works on blocks of 64 rows, one 256-thread workgroup per block, the
+// 64 x 64 operands in LDS, products on the fp64 MFMA (wavefront w: rows / Gram columns 16 w ..), and consecutive steps that need no
+// grid-wide sum in between are one kernel.  Sums over all row blocks (the Grams) leave one 64 x 64 partial per block; a second kernel
+// adds them in block order (deterministic).
+
+// C = At' Bm (64 x 64 x 64, operands in LDS row-major with pitch P65): wavefront w computes rows 16 w .. 16 w + 15 of C
+__device__ __forceinline__ void mm64t_mfma(const double *At, const double *Bm, doublex4 (&acc)[4], int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+#pragma unroll 4
+    for (int ks = 0; ks < B / 4; ks++) {
+        const double a = At[(4 * ks + k4) * P65 + 16 * wave + r16];
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+            acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bm[(4 * ks + k4) * P65 + 16 * tj + r16], acc[tj], 0, 0, 0);
+    }
+}
+// C += A Bm with the accumulators as they come (mm64_mfma zeroes them)
+__device__ __forceinline__ void mm64_mfma_acc(const double *A, const double *Bm, doublex4 (&acc)[4], int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+#pragma unroll 4
+    for (int ks = 0; ks < B / 4; ks++) {
+        const double a = A[(16 * wave + r16) * P65 + 4 * ks + k4];
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+            acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bm[(4 * ks + k4) * P65 + 16 * tj + r16], acc[tj], 0, 0, 0);
+    }
+}
+// 64 rows x 64 columns of a row-major matrix (row stride ld) -> LDS [64][P65]; rows >= rows_valid are zeros
+__device__ __forceinline__ void load64_rows(double *dst, const double *src, long long ld, int rows_valid, int tid)
+{
+    const int i = tid >> 2, j0 = (tid & 3) * 16;
+    if (i < rows_valid) {          // (8-byte loads: the panel's row stride is n, odd for an odd test size)
+#pragma unroll
+        for (int q = 0; q < 16; q++) dst[i * P65 + j0 + q] = src[(long long)i * ld + j0 + q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) dst[i * P65 + j0 + q] = 0.0;
+    }
+}
+// LDS [64 rows r][P65] -> the transposed image: column c of the block becomes 64 consecutive doubles of row (c0 + c) of dstT
+__device__ __forceinline__ void store64_transposed(const double *Z, double *dstT, long long ldt, long long r0, int rows_valid, int tid)
+{
+    const int c = tid >> 2, q0 = (tid & 3) * 16;
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+        if (q0 + q < rows_valid) dstT[(long long)c * ldt + r0 + q0 + q] = Z[(q0 + q) * P65 + c];
+}
+
+// Gram of a tall 64-column matrix by blocks of 64 rows: MUL = false: partial(b) = P_b' P_b;  MUL = true: Q_b = P_b Rinv (written to Q),
+// partial(b) = Q_b' Q_b.  P: m x 64 with row stride ldp; Q: m x 64, row stride 64.
+template <bool MUL>
+__global__ __launch_bounds__(256) void panel_gram_kernel(long long m, const double *P, long long ldp, const double *Rinv, double *Q, double *partials)
+{
+    extern __shared__ double lds[];
+    double *Xs = lds, *Rs = lds + MAT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+    const long long r0 = (long long)blockIdx.x * B;
+    const int rows = (int)((m - r0 < B) ? m - r0 : B);
+    load64_rows(Xs, P + r0 * ldp, ldp, rows, tid);
+    if (MUL) load64(Rs, Rinv, B, tid);
+    __syncthreads();
+    doublex4 acc[4];
+    if (MUL) {
+        mm64_mfma(Xs, Rs, acc, tid);
+        __syncthreads();                                   // every read of P_b is done: Xs takes Q_b
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = 16 * wave + k4 + 4 * e, c = 16 * tj + r16;
+                Xs[i * P65 + c] = acc[tj][e];              // rows past the end are exact zeros (zero rows of P_b)
+                if (i < rows) Q[(r0 + i) * B + c] = acc[tj][e];
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[tj][e] = 0.0;
+    mm64t_mfma(Xs, Xs, acc, tid);
+    double *out = partials + (size_t)blockIdx.x * B * B;
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) out[(16 * wave + k4 + 4 * e) * B + 16 * tj + r16] = acc[tj][e];
+}
+
+// out (64 x 64) = sum over the blocks' partials, in block order
+// (128 workgroups: 32 entries x 8 interleaved classes of blocks each, so that a thread has at most ~20 loads, all in flight at once; a
+// thread per entry walking all ~156 blocks was a latency chain of 8.8 us per sum, three sums per panel)
+__global__ __launch_bounds__(256) void sum_partials_kernel(int nparts, const double *partials, double *out)
+{
+    __shared__ double red[8][33];
+    const int o = threadIdx.x & 31, zs = threadIdx.x >> 5, idx = blockIdx.x * 32 + o;
+    double s = 0.0;
+#pragma unroll 8
+    for (int z = zs; z < nparts; z += 8) s += partials[(size_t)z * B * B + idx];
+    red[zs][o] = s;
+    __syncthreads();
+    if (zs == 0) {
+        double t = red[0][o];
+#pragma unroll
+        for (int q = 1; q < 8; q++) t += red[q][o];
+        out[idx] = t;
+    }
+}
+
+// rows of V below the top block: V_b = Q_b Xm -> [V W] (ld 2b), the reflector store (ld ldv) and the transposed copy [V W]' (rows 0..63);
+// block 0 is the top block the reconstruction kernel wrote: it is only transposed
+__global__ __launch_bounds__(256) void panel_v_kernel(long long m, const double *Q, const double *Xm, double *VW, double *Vst, long long ldv, double *VWt, long long ldt)
+{
+    extern __shared__ double lds[];
+    double *Qs = lds, *Xs = lds + MAT, *Vs = lds + 2 * MAT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+    const long long r0 = (long long)blockIdx.x * B;
+    const int rows = (int)((m - r0 < B) ? m - r0 : B);
+    if (blockIdx.x == 0) {
+        load64_rows(Vs, VW, 2 * B, rows, tid);
+        __syncthreads();
+        store64_transposed(Vs, VWt, ldt, 0, rows, tid);
+        return;
+    }
+    load64_rows(Qs, Q + r0 * B, B, rows, tid);
+    load64(Xs, Xm, B, tid);
+    __syncthreads();
+    doublex4 acc[4];
+    mm64_mfma(Qs, Xs, acc, tid);
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = 16 * wave + k4 + 4 * e, c = 16 * tj + r16;
+            Vs[i * P65 + c] = acc[tj][e];
+            if (i < rows) { VW[(r0 + i) * (2 * B) + c] = acc[tj][e]; Vst[(r0 + i) * ldv + c] = acc[tj][e]; }
+        }
+    __syncthreads();
+    store64_transposed(Vs, VWt, ldt, r0, rows, tid);
+}
+
+// X_b = sum of the split-K slabs of X = A22 V (rows in the aligned coordinates of that product: pad rows in front);
+// Y_b = X_b T -> W columns of [V W];  partial(b) = V_b' Y_b
+__global__ __launch_bounds__(256) void panel_xy_kernel(long long m, long long pad, int slices, const double *slabs, long long slab_stride, const double *T,
+                                                       double *VW, double *partials)
+{
+    extern __shared__ double lds[];
+    double *Xs = lds, *Ts = lds + MAT, *Vs = lds + 2 * MAT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+    const long long r0 = (long long)blockIdx.x * B;
+    const int rows = (int)((m - r0 < B) ? m - r0 : B);
+    {
+        const int i = tid >> 2, j0 = (tid & 3) * 16;
+        double x[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) x[q] = 0.0;
+        if (i < rows)
+            for (int z = 0; z < slices; z++) {
+                const double *src = slabs + (size_t)z * slab_stride + (pad + r0 + i) * B + j0;
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) { const double2 v = *reinterpret_cast<const double2 *>(src + q); x[q] += v.x; x[q + 1] += v.y; }
+            }
+#pragma unroll
+        for (int q = 0; q < 16; q++) Xs[i * P65 + j0 + q] = x[q];
+    }
+    load64(Ts, T, B, tid);
+    load64_rows(Vs, VW + r0 * (2 * B), 2 * B, rows, tid);
+    __syncthreads();
+    doublex4 acc[4];
+    mm64_mfma(Xs, Ts, acc, tid);
+    __syncthreads();                                       // every read of X_b is done: Xs takes Y_b
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = 16 * wave + k4 + 4 * e, c = 16 * tj + r16;
+            Xs[i * P65 + c] = acc[tj][e];
+            if (i < rows) VW[(r0 + i) * (2 * B) + B + c] = acc[tj][e];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[tj][e] = 0.0;
+    mm64t_mfma(Vs, Xs, acc, tid);
+    double *out = partials + (size_t)blockIdx.x * B * B;
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) out[(16 * wave + k4 + 4 * e) * B + 16 * tj + r16] = acc[tj][e];
+}
+
+// M2 = -1/2 T' M1 (every workgroup for itself: 64 MFMAs per wavefront);  W_b = Y_b + V_b M2 -> [V W] and rows 64..127 of [V W]'
+__global__ __launch_bounds__(256) void panel_w_kernel(long long m, const double *T, const double *M1, double *VW, double *VWt, long long ldt)
+{
+    extern __shared__ double lds[];
+    double *Ts = lds, *Ms = lds + MAT, *Vs = lds + 2 * MAT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+    const long long r0 = (long long)blockIdx.x * B;
+    const int rows = (int)((m - r0 < B) ? m - r0 : B);
+    load64(Ts, T, B, tid);
+    load64(Ms, M1, B, tid);
+    load64_rows(Vs, VW + r0 * (2 * B), 2 * B, rows, tid);
+    __syncthreads();
+    doublex4 acc[4];
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[tj][e] = 0.0;
+    mm64t_mfma(Ts, Ms, acc, tid);                          // T' M1
+    __syncthreads();                                       // every read of M1 (and of T) is done: Ms takes M2
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) Ms[(16 * wave + k4 + 4 * e) * P65 + 16 * tj + r16] = -0.5 * acc[tj][e];
+    // the accumulators start from Y_b (in the MFMA's own layout: 16 lanes = 128 consecutive bytes of a row)
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = 16 * wave + k4 + 4 * e;
+            acc[tj][e] = (i < rows) ? VW[(r0 + i) * (2 * B) + B + 16 * tj + r16] : 0.0;
+        }
+    __syncthreads();
+    mm64_mfma_acc(Vs, Ms, acc, tid);                       // Y_b + V_b M2
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = 16 * wave + k4 + 4 * e, c = 16 * tj + r16;
+            Ts[i * P65 + c] = acc[tj][e];                  // T is done with (read before the barrier above)
+            if (i < rows) VW[(r0 + i) * (2 * B) + B + c] = acc[tj][e];
+        }
+    __syncthreads();
+    store64_transposed(Ts, VWt + (size_t)B * ldt, ldt, r0, rows, tid);
+}
+
+// The two-sided update restricted to the NEXT panel's 64 columns (look-ahead): C (m x 64, row stride ldc: rows = the whole trailing matrix,
+// columns = its first 64) -= V W_top' + W V_top', with [V W] the current panel's block vectors (m x 128, row stride 2b) and _top their first
+// 64 rows.  One workgroup per 64 rows; 128 MFMAs per wavefront.  The full update then leaves these columns alone.
+__global__ __launch_bounds__(256) void panel_next_update_kernel(long long m, const double *VW, double *C, long long ldc)
+{
+    extern __shared__ double lds[];
+    double *Vb = lds, *Wb = lds + MAT, *WtT = lds + 2 * MAT, *VtT = lds + 3 * MAT;      // V_b, W_b (negated) | W_top', V_top' (k-major)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+    const long long r0 = (long long)blockIdx.x * B;
+    const int rows = (int)((m - r0 < B) ? m - r0 : B);
+    {
+        const int i = tid >> 2, j0 = (tid & 3) * 16;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const double v = (i < rows) ? VW[(r0 + i) * (2 * B) + j0 + q] : 0.0, w_ = (i < rows) ? VW[(r0 + i) * (2 * B) + B + j0 + q] : 0.0;
+            Vb[i * P65 + j0 + q] = -v;
+            Wb[i * P65 + j0 + q] = -w_;
+            // top block, transposed: WtT[k][c] = W[c][k], VtT[k][c] = V[c][k]   (i = c here; the panel has more than 64 rows)
+            WtT[(j0 + q) * P65 + i] = VW[(long long)i * (2 * B) + B + j0 + q];
+            VtT[(j0 + q) * P65 + i] = VW[(long long)i * (2 * B) + j0 + q];
+        }
+    }
+    doublex4 acc[4];
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = 16 * wave + k4 + 4 * e;
+            acc[tj][e] = (i < rows) ? C[(r0 + i) * ldc + 16 * tj + r16] : 0.0;
+        }
+    __syncthreads();
+    mm64_mfma_acc(Vb, WtT, acc, tid);
+    mm64_mfma_acc(Wb, VtT, acc, tid);
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = 16 * wave + k4 + 4 * e;
+            if (i < rows) C[(r0 + i) * ldc + 16 * tj + r16] = acc[tj][e];
+        }
+}
+
 // =================================================================================================================================
+// doubles of the stage-1 panel work space: two transposed copies [V W]' (128 x ldt each) + one 64 x 64 Gram partial per block of 64 rows
+static size_t sb2_panel_work(int n)
+{
+    const size_t ldt = ((size_t)n + 128 + 127) / 128 * 128;
+    return 2 * 128 * ldt + ((size_t)n / B + 2) * B * B;
+}
 size_t sb2_bytes(int n)
 {
     const size_t nn = (size_t)n * n;
     const size_t ng = ((size_t)n + SB_G - 1) / SB_G + 1, kmax = ((size_t)n + B - 1) / B + 1;
     return 8 * (2 * nn + (size_t)n * 4 * B + (size_t)n * SB_LD + (size_t)n * (kmax + 1) + 2 * ng * kmax * 128 * SB_G + (kmax + 1) * SB_G * n +
-                (ng + 1) * B * B + 2 * (size_t)BT1_BLOCK * BT1_BLOCK + 2 * (size_t)BT1_BLOCK * n + 64 * B * B + (kmax + 1) * SB_MAIL_LD) + 4 * ((size_t)n + 64);
+                (ng + 1) * B * B + 2 * (size_t)BT1_BLOCK * BT1_BLOCK + 2 * (size_t)BT1_BLOCK * n + 64 * B * B + (kmax + 1) * SB_MAIL_LD + sb2_panel_work(n)) +
+           4 * ((size_t)n + 64) + 4096;
 }
 
 thread_local DevArena *g_arena = nullptr;
@@ -536,7 +825,8 @@ int sb2_alloc(int n, Sb2Work &w)
         {&w.Vst, nn}, {&w.Tst, (size_t)(w.npan + 1) * B * B}, {&w.VW, ((size_t)n + 384) * 2 * B}, {&w.Qb, ((size_t)n + 384) * B}, {&w.sm, (size_t)16 * B * B},
         {&w.S, ((size_t)n + 2) * SB_LD}, {&w.VV, nn}, {&w.TAU, (size_t)n * w.nk}, {&w.Vp, (size_t)w.ng * w.kmax * 128 * SB_G},
         {&w.Vtp, (size_t)w.ng * w.kmax * 128 * SB_G}, {&w.Wws, ((size_t)w.kmax + 1) * SB_G * n}, {&w.G, (size_t)BT1_BLOCK * BT1_BLOCK},
-        {&w.T, (size_t)BT1_BLOCK * BT1_BLOCK}, {&w.W, (size_t)BT1_BLOCK * n}, {&w.W2, (size_t)BT1_BLOCK * n}, {&w.mail, ((size_t)w.kmax + 1) * SB_MAIL_LD}};
+        {&w.T, (size_t)BT1_BLOCK * BT1_BLOCK}, {&w.W, (size_t)BT1_BLOCK * n}, {&w.W2, (size_t)BT1_BLOCK * n}, {&w.mail, ((size_t)w.kmax + 1) * SB_MAIL_LD},
+        {&w.Pw, sb2_panel_work(n)}};
     for (auto &r : req) { if (!rc) rc = alloc_d2(r.p, r.cnt); }
     if (!rc) rc = dev_alloc(reinterpret_cast<void **>(&w.prog), ((size_t)n + 16) * sizeof(int));
     if (!rc) rc = dev_alloc(reinterpret_cast<void **>(&w.fail), 4 * sizeof(int));
@@ -546,7 +836,7 @@ int sb2_alloc(int n, Sb2Work &w)
 
 void sb2_free(Sb2Work &w)
 {
-    for (double *p : {w.Vst, w.Tst, w.VW, w.Qb, w.sm, w.S, w.VV, w.TAU, w.Vp, w.Vtp, w.Wws, w.G, w.T, w.W, w.W2, w.mail}) dev_free(p);
+    for (double *p : {w.Vst, w.Tst, w.VW, w.Qb, w.sm, w.S, w.VV, w.TAU, w.Vp, w.Vtp, w.Wws, w.G, w.T, w.W, w.W2, w.mail, w.Pw}) dev_free(p);
     dev_free(w.prog);
     dev_free(w.fail);
     w = Sb2Work{};
@@ -573,8 +863,20 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
     // transposed copy of [V W] for the rank-128 update (the back-transformation's work space is free during stage 1): 128 rows of
     // ldt doubles, the panel's rows from column 128 on, the 128 columns in front kept zero
     const long long ldt = ((long long)n + 128 + 127) / 128 * 128;
-    double *const VWt = w.Wws;
-    PG_HIP(hipMemsetAsync(VWt, 0, (size_t)128 * ldt * 8, st));
+    // two copies, used by alternating panels (with look-ahead the next panel's V is written while the update still reads this one's),
+    // then the Gram partials of the fused panel kernels: one 64 x 64 block per 64 rows
+    double *const VWt_base = w.Pw;
+    auto VWt_of = [&](int pan_) { return VWt_base + (size_t)(pan_ & 1) * 128 * ldt; };
+    double *const parts = VWt_base + (size_t)2 * 128 * ldt;
+    PG_HIP(hipMemsetAsync(VWt_base, 0, (size_t)2 * 128 * ldt * 8, st));
+    bool fused = n >= 2 * B + 2;
+    if (const char *e_ = getenv("PG_SB2_FUSED")) fused = fused && atoi(e_) != 0;      // A/B timing and tests
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gram_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAT * 8));
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gram_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAT * 8));
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_v_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * MAT * 8));
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_xy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * MAT * 8));
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * MAT * 8));
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_next_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * MAT * 8));
     double *sm = w.sm;
     auto SM = [&](int k) { return sm + (size_t)k * B * B; };
     const long long ld = n;
@@ -586,7 +888,18 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
         double *Vs = w.Vst + (size_t)(j + B) * ld + j;
         double *Tp = w.Tst + (size_t)pan * B * B;
         int rc = PG_OK;
-        if (m > B) {
+        if (m > B && fused) {
+            // CholeskyQR2 with the fused panel kernels: Gram partials per block of 64 rows + their sum; R1, R1^-1; Q1 = P R1^-1 and the
+            // partials of G2 = Q1'Q1 in one kernel; reconstruction; V = Q1 Xm straight into [V W], the reflector store and [V W]'
+            const unsigned nb = (unsigned)((m + B - 1) / B);
+            panel_gram_kernel<false><<<nb, 256, 2 * MAT * 8, cs>>>(m, P, ld, nullptr, nullptr, parts);
+            sum_partials_kernel<<<B * B / 32, 256, 0, cs>>>((int)nb, parts, SM(SM_G1));
+            chol_inv_kernel<<<1, 64, CHOL_LDS, cs>>>(SM(SM_G1), SM(SM_R1), SM(SM_R1INV), w.fail);
+            panel_gram_kernel<true><<<nb, 256, 2 * MAT * 8, cs>>>(m, P, ld, SM(SM_R1INV), Qb0, parts);
+            sum_partials_kernel<<<B * B / 32, 256, 0, cs>>>((int)nb, parts, SM(SM_G2));
+            recon_kernel<<<1, 256, 3 * MAT * 8, cs>>>(SM(SM_G2), SM(SM_R1), Qb0, P, ld, VW0, Vs, ld, Tp, SM(SM_XM), SM(SM_RPROD), w.fail);
+            panel_v_kernel<<<nb, 256, 3 * MAT * 8, cs>>>(m, Qb0, SM(SM_XM), VW0, Vs, ld, VWt_of(pan) + 128, ldt);
+        } else if (m > B) {
             // CholeskyQR2: G1 = P'P, R1; Q1 = P R1^-1; G2 = Q1'Q1, R2; (Q = Q1 R2^-1 only through its top block and Xm)
             rc = dgemm(c, true, B, B, m, 1.0, P, ld, P, ld, 0.0, SM(SM_G1), B);
             if (rc) return rc;
@@ -617,13 +930,18 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
     hipEvent_t e_col = nullptr, e_fac = nullptr;
     bool ahead = false;
     if (const char *e_ = getenv("PG_SB2_LOOKAHEAD")) {
-        const int reserve = std::max(1, std::min(atoi(e_), ctx->num_cu / 2));
-        uint32_t mask[16];
-        const int words = (ctx->num_cu + 31) / 32;
-        for (int q = 0; q < 16; q++) mask[q] = 0;
-        for (int c = reserve; c < ctx->num_cu; c++) mask[c / 32] |= 1u << (c % 32);
-        ahead = words <= 16 && hipExtStreamCreateWithCUMask(&side.stream, (uint32_t)words, mask) == hipSuccess &&
-                hipEventCreateWithFlags(&e_col, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e_fac, hipEventDisableTiming) == hipSuccess;
+        const int req = atoi(e_);
+        bool ok;
+        if (req < 0) ok = hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking) == hipSuccess;       // -1: a plain second stream
+        else {
+            const int reserve = std::max(1, std::min(req, ctx->num_cu / 2));
+            uint32_t mask[16];
+            const int words = (ctx->num_cu + 31) / 32;
+            for (int q = 0; q < 16; q++) mask[q] = 0;
+            for (int c = reserve; c < ctx->num_cu; c++) mask[c / 32] |= 1u << (c % 32);
+            ok = words <= 16 && hipExtStreamCreateWithCUMask(&side.stream, (uint32_t)words, mask) == hipSuccess;
+        }
+        ahead = req != 0 && ok && hipEventCreateWithFlags(&e_col, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e_fac, hipEventDisableTiming) == hipSuccess;
         if (!ahead) (void)hipGetLastError();
     }
     auto finish = [&](int rc) {
@@ -646,26 +964,66 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
         const long long off = j + B, off_al = off & ~(long long)127, pad = off - off_al;      // pad = 0 or 64
         double *A22al = A + (size_t)off_al * ld + off_al;
         double *V = VW0, *Wc = VW0 + B;                           // columns 0..63 / 64..127 of VW (ld 128)
+        double *const VWt = VWt_of(pan);
+        DgemmDesc::Partials xp;
         {   // X = A22 V: A22 symmetric with its lower triangle (+ diagonal tiles) valid
             DgemmDesc d;
             d.symA = true; d.M = m + pad; d.N = B; d.K = m + pad; d.alpha = 1.0; d.beta = 0.0;
             d.A = A22al; d.lda = ld; d.B = VW0 - (size_t)pad * 2 * B; d.ldb = 2 * B; d.C = Qb0 - (size_t)pad * B; d.ldc = B;
+            if (fused && m > B) d.partials = &xp;            // the slices of a split K are summed by the kernel that consumes X
             rc = dgemm_ex(ctx, d);
         }
-        if (!rc) rc = dgemm(ctx, false, m, B, B, 1.0, Qb0, B, Tp, B, 0.0, Wc, 2 * B);               // Y  = X T           -> W columns
-        if (!rc) rc = dgemm(ctx, true, B, B, m, 1.0, V, 2 * B, Wc, 2 * B, 0.0, SM(SM_M1), B);       // M1 = V' Y
-        if (!rc) rc = dgemm(ctx, true, B, B, B, -0.5, Tp, B, SM(SM_M1), B, 0.0, SM(SM_M2), B);      // M2 = -1/2 T' M1
-        if (!rc) rc = dgemm(ctx, false, m, B, B, 1.0, V, 2 * B, SM(SM_M2), B, 1.0, Wc, 2 * B);      // W  = Y + V M2
-        if (rc) return finish(rc);
-        transpose_vw_kernel<<<dim3((unsigned)((m + 63) / 64), 2), 256, 0, st>>>(m, VW0, VWt + 128, ldt);
-        if (hipGetLastError() != hipSuccess) return finish(PG_EHIP);
+        if (fused && m > B) {
+            if (rc) return finish(rc);
+            const unsigned nb = (unsigned)((m + B - 1) / B);
+            const double *slabs = (xp.slices > 1) ? xp.ws : Qb0 - (size_t)pad * B;
+            panel_xy_kernel<<<nb, 256, 3 * MAT * 8, st>>>(m, pad, xp.slices, slabs, (m + pad) * B, Tp, VW0, parts);      // Y = X T, partials of V'Y
+            sum_partials_kernel<<<B * B / 32, 256, 0, st>>>((int)nb, parts, SM(SM_M1));
+            panel_w_kernel<<<nb, 256, 3 * MAT * 8, st>>>(m, Tp, SM(SM_M1), VW0, VWt + 128, ldt);                            // W = Y - 1/2 V T'(V'Y)
+            if (hipGetLastError() != hipSuccess) return finish(PG_EHIP);
+        } else {
+            if (!rc) rc = dgemm(ctx, false, m, B, B, 1.0, Qb0, B, Tp, B, 0.0, Wc, 2 * B);               // Y  = X T           -> W columns
+            if (!rc) rc = dgemm(ctx, true, B, B, m, 1.0, V, 2 * B, Wc, 2 * B, 0.0, SM(SM_M1), B);       // M1 = V' Y
+            if (!rc) rc = dgemm(ctx, true, B, B, B, -0.5, Tp, B, SM(SM_M1), B, 0.0, SM(SM_M2), B);      // M2 = -1/2 T' M1
+            if (!rc) rc = dgemm(ctx, false, m, B, B, 1.0, V, 2 * B, SM(SM_M2), B, 1.0, Wc, 2 * B);      // W  = Y + V M2
+            if (rc) return finish(rc);
+            transpose_vw_kernel<<<dim3((unsigned)((m + 63) / 64), 2), 256, 0, st>>>(m, VW0, VWt + 128, ldt);
+            if (hipGetLastError() != hipSuccess) return finish(PG_EHIP);
+        }
         // A22 -= [V W] [W V]' on the lower triangle: first tile column, then (beside the next panel's factorisation) the rest
         const long long mm = m + pad;
         const bool next = n - (j + B) - B >= 2;
         DgemmDesc d;
         d.transA = true; d.kxorB = B; d.K = 2 * B; d.alpha = -1.0; d.beta = 1.0; d.lower_only = true; d.lda = ldt; d.ldb = ldt; d.ldc = ld;
-        const bool split = ahead && next && mm > 128;
+        const bool split = ahead && next && mm > 128 && m > B;
         factored = false;
+        if (split && fused) {
+            // Look-ahead (r4).  The next panel is the trailing matrix's first 64 columns: they are updated first, by a thin kernel of its
+            // own (6 us; the first 128-column tile column as a GEMM launch took 54: ~60 tiles on 256 CUs), the next factorisation follows
+            // on this stream; everything else of the update goes to the second stream: the other half of tile column 0 (aligned columns
+            // 64..127; only when the trailing matrix starts on a tile boundary — otherwise that tile column is the 64 zero columns in front
+            // and the next panel, nothing more) as a 64-wide strip, and the lower triangle of the tiles from (1, 1) on.
+            if (hipEventRecord(e_col, st) != hipSuccess) return finish(PG_EHIP);
+            if (hipStreamWaitEvent(side.stream, e_col, 0) != hipSuccess) return finish(PG_EHIP);
+            if (pad == 0) {
+                DgemmDesc s_ = d;
+                s_.lower_only = false; s_.M = mm; s_.N = B;
+                s_.A = VWt + 128; s_.B = VWt + 128 + B; s_.C = A22al + B;
+                rc = dgemm_ex(&side, s_);
+                if (rc) return finish(rc);
+            }
+            d.M = mm - 128; d.N = mm - 128;
+            d.A = VWt + 128 - pad + 128; d.B = d.A; d.C = A22al + (size_t)128 * ld + 128;
+            rc = dgemm_ex(&side, d);
+            if (rc) return finish(rc);
+            if (hipEventRecord(e_fac, side.stream) != hipSuccess) return finish(PG_EHIP);
+            panel_next_update_kernel<<<(unsigned)((m + B - 1) / B), 256, 4 * MAT * 8, st>>>(m, VW0, A + (size_t)off * ld + off, ld);
+            if (hipGetLastError() != hipSuccess) return finish(PG_EHIP);
+            rc = factor(ctx, j + B, pan + 1);
+            if (rc) return finish(rc);
+            factored = true;
+            continue;
+        }
         if (split) {
             // the part of the update beyond the first tile column: on the masked stream, as soon as [V W]' is there
             if (hipEventRecord(e_col, st) != hipSuccess) return finish(PG_EHIP);

@@ -24,6 +24,7 @@ struct Sb2Work {
     double *Wws = nullptr;    // (kmax + 1) x SB_G x n
     double *G = nullptr, *T = nullptr, *W = nullptr, *W2 = nullptr;   // stage-1 back-transformation (blocks of 256 reflectors)
     double *mail = nullptr;   // (kmax + 1) x SB_MAIL_LD: mailboxes of the stationary bulge-chasing kernel
+    double *Pw = nullptr;     // stage-1 panel work: two transposed copies [V W]' (128 x ldt) + the Gram partials of the fused panel kernels
     int *prog = nullptr;      // n + 16 ints: per-sweep progress | work-queue head | abort flag
     int *fail = nullptr;      // 4 ints: [0] panel factorisation lost orthogonality / not positive definite, [1] bulge-chase wait expired
 };

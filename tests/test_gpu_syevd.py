@@ -95,6 +95,24 @@ def test_dgemm_rank_2b_update_on_the_lower_triangle(m, pad, ctx):
     assert (got[:, :mm][~low] == Cm[:, :mm][~low]).all()
 
 
+def test_dgemm_lower_update_of_one_tile_column(ctx):
+    """The look-ahead of the band reduction updates the first tile column on its own: C is rectangular (m x 128), lower_only still
+    skips the tile above the diagonal (there is none in column 0) — and a rectangular lower C of two tile columns skips tile (0, 1)."""
+    rng = np.random.default_rng(3)
+    m, ldt = 900, 1152
+    VWt = np.zeros((128, ldt)); VWt[:, :m] = rng.standard_normal((128, m))
+    V, W = VWt[:64, :m].T, VWt[64:, :m].T
+    full = V @ W.T + W @ V.T
+    for N in (128, 256):
+        Cm = rng.standard_normal((m, N))
+        got = _dgemm_ex(ctx, TA | LOW, 64, m, N, 128, -1.0, VWt, ldt, VWt, ldt, 1.0, Cm, N)
+        ref = Cm - full[:, :N]
+        i, j = np.indices((m, N))
+        low = (j // 128) <= (i // 128)
+        assert np.abs(got - ref)[low].max() <= 1e-12
+        assert (got[~low] == Cm[~low]).all()
+
+
 @pytest.mark.parametrize("m,N,split", [(640, 64, 0), (1000, 64, 0), (2304, 64, 1), (2304, 64, 0), (777, 128, 0), (1290, 192, 1)])
 def test_dgemm_symmetric_A_from_its_lower_triangle(m, N, split, ctx):
     """X = A V with A symmetric and only its lower triangle + the full 128 x 128 diagonal tiles valid (the rest is NaN here and must never
