@@ -25,6 +25,7 @@
 namespace pg {
 
 typedef double doublex4 __attribute__((ext_vector_type(4)));
+typedef double doublex2 __attribute__((ext_vector_type(2)));
 
 #ifndef PG_DBK
 #define PG_DBK 8
