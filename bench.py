@@ -417,6 +417,11 @@ def main():
         "roofline": rl_assoc if assoc_avg >= rot_avg else rl_rotate,
         "roofline_rotate": rl_rotate,
         "roofline_assoc": rl_assoc,
+        # the metric names the eigendecomposition too: its 10 n^3 / 3 flops (tridiagonalisation 4/3 + back-transformation 2: the count of a
+        # one-stage LAPACK dsyevd; the two-stage solver executes more) against the fp64 MFMA peak
+        "roofline_eigh": ({"bound": "mfma", "achieved": 10.0 * n ** 3 / 3.0 / min(eigh_s) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                           "frac": 10.0 * n ** 3 / 3.0 / min(eigh_s) / 78.6e12, "flop_model": "10 n^3 / 3 (dsyevd count) / eigh_seconds",
+                           "by_phase": "profiles/r04_syevd_summary.json"} if eigh_s else None),
         "rotation_path": "fp32 MFMA (reference-arithmetic sgemm class)" if not used_geno else "genotype f16x2",
         "stage_snps_per_s_per_gpu": {"rotate": B / rot_avg, "assoc": B / assoc_avg},
         "evals_per_snp": {"fast": float(stats[0]), "newton": float(stats[1])},

@@ -802,8 +802,10 @@ __device__ __forceinline__ float newton_dev(const AssocParams &pr, float lroot, 
 }
 
 template <int C, bool LRT>
-// two waves per SIMD: a lone wave cannot issue fp64 VALU at the pipe's rate (measured 2.3x faster at 2 than at 1;
-// <= 256 VGPRs at c <= 6 with a handful of spills outside the hot loops); larger c keeps one wave and its registers
+// two waves per SIMD for EVERY c (PG_WAVES = 2): a lone wave cannot issue fp64 VALU at the pipe's rate (measured 2.3x faster at 2 than at
+// 1).  From c = 4 on the instantiations are capped at 256 VGPRs with spills to scratch (c = 5: 58 VGPR + 35 SGPR spills, 196 B; c = 10:
+// 107, 320 B; c = 14: 276 B) — all of them in the per-evaluation outer loops; the Gram loops themselves are scratch-free (checked on the
+// shipped code object: VERDICT r3)
 __global__ __launch_bounds__(64 * WPB, PG_WAVES) void assoc_kernel(AssocParams pr)
 {
     constexpr int M = Shape<C>::M, NP = Shape<C>::NP, SLOTS = Shape<C>::SLOTS;

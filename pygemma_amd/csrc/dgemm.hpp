@@ -50,7 +50,7 @@ struct DgemmParams {
     int symA;                               // TA = false only; needs 128-row tiles (WMI = 4) and lda = row stride of the symmetric matrix
     int vecC;                               // C base, ldc and strideC allow 16-byte accesses
     long long *stamps;                      // diagnostics: in-kernel time stamps of one workgroup (nullptr: none)
-    int tune;                               // ring kernel experiments (PG_DGEMM_TUNE): bit 0 s_setprio around the products, bit 1 start-up stagger
+    int tune;                               // diagnostics (PG_DGEMM_TUNE): bit 3 in-kernel stamps, bit 5 one workgroup per CU, bit 7 DMA issued in one block
 };
 
 template <bool TA, bool TB, int WMI, int WNI, bool SYM>
@@ -323,7 +323,6 @@ __device__ __forceinline__ void ring_dma16(const double *src, unsigned char *dst
 }
 
 // in-kernel time stamps of ONE workgroup (PG_DGEMM_TUNE bit 3; blockIdx.x == 300): where a tile's time goes — diagnostics only
-static __device__ int g_cu_ticket[2048];      // arrivals per physical CU (start-up stagger experiment, PG_DGEMM_TUNE bit 1)
 extern long long *g_ring_stamp_buf;      // device buffer of 64 stamps (syevd.hip: pgx_ring_stamps), nullptr until asked for
 #define RING_STAMP(ix) do { if (stamp) gp.stamps[ix] = __builtin_amdgcn_s_memtime(); } while (0)
 
@@ -332,22 +331,12 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
 {
     const bool stamp = gp.stamps != nullptr && blockIdx.x == 300 && blockIdx.y == 0 && threadIdx.x == 0;
     RING_STAMP(0);
-    // Two workgroups share a CU, one wave of each per SIMD.  With equal priority the SIMD's arbiter alternates between their MFMAs, both
-    // finish a chunk's 32 products together and then do their per-chunk overhead (waits, barrier, DMA issue: ~1 500 cycles) together —
-    // the matrix pipe idles meanwhile (5 600 cycles per chunk where 4 096 are products: in-kernel stamps, r4).  Unequal priorities break the
-    // symmetry: the wave in the odd wave slot of its SIMD always wins, runs as if alone, and the other one fills every gap it leaves.
-    if (gp.tune & 64) {       // measured: no effect on any shape (r4) — kept as an experiment switch
-        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));    // HW_REG_HW_ID, bits 3:0 = wave slot in the SIMD
-        if (hw & 1) __builtin_amdgcn_s_setprio(2);
-    }
     constexpr int DBM = 128, DBN = 32 * WNI;
     constexpr int BROW = DBN * 8;                       // bytes of one k-row of the B image (and of one row of a staged C group)
     constexpr int SLOT_A = 8192, SLOT = SLOT_A + RBK * BROW;
     constexpr int NI = (WNI == 4) ? 4 : 3;              // DMA instructions per wave and operand chunk
     constexpr int NC = (WNI == 4) ? 4 : 2;              // ... per staged C group, and global stores per wave and group
-    // dynamic: RS slots + 4 KB that nothing reads (the landing area of the C prefetch below); above 64 KB only dynamic LDS is honoured
-    extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
-    unsigned char *const dummy = ring + RS * SLOT;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];      // RS slots (dynamic: the launch may add idle LDS, PG_DGEMM_TUNE bit 5)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const long long M = gp.M, N = gp.N;
@@ -451,21 +440,6 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
             }
         }
     };
-    // C prefetch: the tile's 128 KB cannot wait in LDS, but it can wait in L2 / the memory-side cache.  During the last 16 chunks every
-    // wave touches two rows of the tile per chunk with an LDS-DMA whose LDS side nobody reads; the real DMA of the row groups then finds
-    // the lines on chip (without this the 8 short epilogue steps each waited a loaded HBM round trip: 27 of a tile's 103 kilocycles).
-    const bool pfC = rdC && WNI == 4 && (gp.tune & 4);     // measured: no gain (r4 call 5) — off unless PG_DGEMM_TUNE bit 2
-    const int pf_start = (NCH > 16) ? NCH - 16 : 0;
-    auto PF = [&](int t) { return (pfC && t >= pf_start && t < NCH && t >= 0) ? 2 : 0; };
-    auto prefetch = [&](int t) {
-        if (PF(t) == 0) return;
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            int row = (t - pf_start) * 8 + 2 * wave + u;
-            row = row < DBM ? row : DBM - 1;
-            ring_dma16(Cp + (m0 + row) * ldc + n0 + 2 * lane, dummy + wave * 1024);
-        }
-    };
     // one DMA instruction of virtual chunk x (operand chunk: A piece 0, 1, then B; C group: its rows): issued BETWEEN the products of the
     // chunk being multiplied — an MFMA holds the wave's issue port for 8 of its 64 cycles, so a DMA's ~120 issue cycles disappear in the
     // shadow of the products; issued in one block before them they were 480 of a chunk's 3 200 cycles (in-kernel stamps, r4)
@@ -542,23 +516,6 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
     // ---- prologue: the first three chunks are on their way before anything else happens
     issue(0); issue(1); issue(2);
     RING_STAMP(1);
-    bool hold_me = false;
-    if ((gp.tune & 2) && blockIdx.x < 2 * 256) {
-        // first-round workgroups take a ticket on their physical CU (XCC, SE, SH, CU from the hardware id registers): the second to arrive waits
-        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (8 << 6) | ((8 - 1) << 11));       // HW_ID bits 15:8: CU_ID, SH_ID, SE_ID
-        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11));     // XCC_ID bits 3:0
-        __shared__ int tk_sh;
-        if (threadIdx.x == 0) tk_sh = atomicAdd(&g_cu_ticket[((xcc & 7) << 8) | (hw & 255)], 1);
-        __syncthreads();
-        hold_me = (tk_sh & 1) != 0;
-    }
-    if (hold_me) {
-        // the two workgroups of a CU start together and take equally long: without this they stay in phase — both in their products, then
-        // both in their epilogues, the matrix pipe idle meanwhile.  The workgroups of the second dispatch round per CU start half a tile late.
-        const long long t0 = wall_clock64();
-        const long long hold = (long long)(gp.tune >> 8) * 100;   // microseconds in bits 8.. of PG_DGEMM_TUNE -> 100 MHz ticks
-        while (wall_clock64() - t0 < hold) __builtin_amdgcn_s_sleep(8);
-    }
     if (ktail > 0) {
         // the last, partial chunk by hand into slot 3 (its rows past the end are zeros), multiplied first; chunk 3's DMA is issued behind
         // the barrier of iteration 0, i.e. after every wave has read this
@@ -583,15 +540,14 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
         mfma_chunk(sl, km, -1);
     }
     // ---- main loop: one barrier per chunk
-    const bool pf_any = pfC;
     for (int t = 0; t < NCH; t++) {
         if (t == 8) RING_STAMP(32);
         // steady state (two operand chunks younger than the one waited for, no prefetch in flight): an immediate — the computed count
         // below is a 30-way compare chain of ~400 cycles, paid per chunk
-        if (t + 2 < NCH && !pf_any) {
+        if (t + 2 < NCH) {
             if (NI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else ring_wait_vm(PF(t - 3) + cnt(t + 1) + PF(t - 2) + cnt(t + 2) + PF(t - 1));
+        } else ring_wait_vm(cnt(t + 1) + cnt(t + 2));
         if (t == 8) RING_STAMP(33);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -601,7 +557,6 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
         if (t == 8) RING_STAMP(4);
         if (gp.tune & 128) issue(t + 3);          // A/B: the DMA in one block before the products (as until r4 call 9)
         if (t == 8) RING_STAMP(34);
-        prefetch(t);
         if (t == 8) RING_STAMP(35);
         mfma_chunk(ring + (t & (RS - 1)) * SLOT, chunk_km(kbeg + (long long)t * RBK), (gp.tune & 128) ? -1 : t + 3);
         if (t == 8) RING_STAMP(36);
@@ -616,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_ring_kernel(DgemmParams gp)
             unsigned char *sl = ring + (t & (RS - 1)) * SLOT;
             // younger than group g's DMA: the DMAs of groups g + 1, g + 2 and the stores of groups g - 3 .. g - 1
             const int st = NC * ((g >= 3) ? 3 : g);
-            ring_wait_vm(cnt(t + 1) + cnt(t + 2) + st + PF(t - 3) + PF(t - 2) + PF(t - 1));
+            ring_wait_vm(cnt(t + 1) + cnt(t + 2) + st);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -780,7 +735,7 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
         gp.lower = tri ? 1 : (d.lower_only ? 2 : 0);
         const long long T = tri ? tm_ * (tm_ + 1) / 2 : tm_ * tn_;
         dim3 rgrid((unsigned)T, (unsigned)ksplit, 1);
-        constexpr int LDS4 = RS * (8192 + RBK * 1024) + 4096, LDS2 = RS * (8192 + RBK * 512) + 4096;
+        constexpr int LDS4 = RS * (8192 + RBK * 1024), LDS2 = RS * (8192 + RBK * 512);
         {   // the 128-wide variants take 68 KB of dynamic LDS: a per-DEVICE function attribute, set on a device's first call
             static std::atomic<unsigned> done_mask{0};
             const unsigned bit = 1u << (ctx->device & 31);

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-3 records of the two-stage eigensolver at n = 10 000 (run through gpurun from the repo root):
+# Records of the two-stage eigensolver at n = 10 000 (run through gpurun from the repo root):
 #   phase timers (PG_SYEVD_TIMING), rocprofv3 --kernel-trace of one solve, one --pmc pass (MFMA-busy cycles) on the same command.
 # tools/summarize_syevd.py condenses them into profiles/<tag>_syevd_summary.json
-TAG=${1:-r03}
+TAG=${1:-r04}
 N=${2:-10000}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_${TAG}_syevd

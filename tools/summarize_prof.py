@@ -44,7 +44,7 @@ n, B = int(_cfg["n"]), int(_cfg["batch"])          # the PMC passes run bench.py
 npad = (n + 63) // 64 * 64
 summ = {"note": "MI355X, 1 GPU. kernel_stats: rocprofv3 --kernel-trace --stats of `python3 bench.py --e2e 0 --cpu-sample 0` (the bench's timed command). "
                 "pmc: separate rocprofv3 --kernel-trace --pmc passes (one counter group per run) on bench.py ITSELF (--steps 2 --warmup 1, eigenpairs "
-                "from --eigh-cache; full 16384-SNP batches only). FETCH_SIZE/WRITE_SIZE are KB; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide "
+                "from --eigh-cache; full batches of the bench's own --batch only (default: one 100 000-SNP batch)). FETCH_SIZE/WRITE_SIZE are KB; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide "
                 "coalesced reads by 2x on gfx950, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (fabric side of L2: Infinity-Cache hits included). "
                 "Pipe-busy: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8); VALU issue = 4 cycles * SQ_INSTS_VALU / the same; "
                 "clock = GRBM_GUI_ACTIVE / 8 / duration. pmc_full_bench: bench.py including the eigensolver under --pmc (the library drains the stream once per panel)."}

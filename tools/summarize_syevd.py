@@ -53,9 +53,18 @@ def phase_of(names):
             "back-transform 2": (bt2[0], bt2[-1] + 1), "back-transform 1": (bt2[-1] + 1, len(names))}
 
 
+upd = ("rank-128 update A22 -= [V W][W V]', lower triangle: sum_panels 2 (m^2/2) 128", sum(2 * (m * m / 2) * 128 for m in ms))
+symx = ("X = A22 V, A22 symmetric from its lower triangle: sum_panels 2 m^2 64", sum(2 * m * m * 64 for m in ms))
+bt1a = ("W = V'Z and G = V'V per block of 256 reflectors", sum(2 * m * n * r + 2 * m * m * r for m, r in bt1))
+bt1b = ("Z -= V (T W) and T W", sum(2 * r * n * m + 2 * m * m * n for m, r in bt1))
 flops = {
-    ("dense->band", "dgemm_kernel<true, false, 4, 4, false>"): ("rank-128 update A22 -= [V W][W V]', lower triangle: sum_panels 2 (m^2/2) 128", sum(2 * (m * m / 2) * 128 for m in ms)),
-    ("dense->band", "dgemm_kernel<false, false, 4, 2, true>"): ("X = A22 V, A22 symmetric from its lower triangle: sum_panels 2 m^2 64", sum(2 * m * m * 64 for m in ms)),
+    # r3 names (register-staged kernel) and r4 names (LDS-DMA ring kernel: <A k-major, symmetric A, 16-column tiles per wave>)
+    ("dense->band", "dgemm_kernel<true, false, 4, 4, false>"): upd,
+    ("dense->band", "dgemm_ring_kernel<true, false, 4>"): upd,
+    ("dense->band", "dgemm_kernel<false, false, 4, 2, true>"): symx,
+    ("dense->band", "dgemm_ring_kernel<false, true, 2>"): symx,
+    ("back-transform 1", "dgemm_ring_kernel<true, false, 4>"): bt1a,
+    ("back-transform 1", "dgemm_ring_kernel<false, false, 4>"): bt1b,
     ("back-transform 2", "bt2_apply4_kernel"): ("four reflector blocks per slab trip; flops EXECUTED = 46 of the 64 tile products of a zero-padded 128 x 64 block: per block 46/64 x 2 x (2 x 128 x 64 x n)",
                                                nblk * (46 / 64) * 2 * (2 * 128 * 64 * n)),
     ("back-transform 1", "dgemm_kernel<true, false, 4, 4, false>"): ("W = V'Z and G = V'V per block of 256 reflectors", sum(2 * m * n * r + 2 * m * m * r for m, r in bt1)),
@@ -64,7 +73,7 @@ flops = {
 names = [short(r["Kernel_Name"]) for r in tr]
 out = {"note": f"MI355X, one pg_syevd_dev solve at n = {n} (two-stage), rocprofv3 --kernel-trace, kernels grouped by phase (position in the stream); mfma_busy and clock "
                "are per kernel NAME over the whole solve, from a separate --pmc pass: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), clock = "
-               "GRBM_GUI_ACTIVE / 8 / duration.  useful_TF counts the flops named in `what` only; fp64 MFMA peak 78.6 TF.",
+               "GRBM_GUI_ACTIVE / 8 / duration (both only for kernels averaging >= 50 us per dispatch).  useful_TF counts the flops named in `what` only; fp64 MFMA peak 78.6 TF.",
        "timing": open(os.path.join(D, "timing.txt")).read().splitlines()[-14:], "phases": []}
 for ph, (a, z) in phase_of(names).items():
     agg = collections.defaultdict(lambda: [0, 0.0])
@@ -74,7 +83,9 @@ for ph, (a, z) in phase_of(names).items():
     ks = []
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:10]:
         e = {"kernel": k, "calls": c, "total_ms": round(t, 3)}
-        if k in pm and pm[k].get("GRBM_GUI_ACTIVE"):
+        # GRBM_GUI_ACTIVE / 8 / duration reads high on dispatches of a few microseconds (the guide: reliable from ~0.3 ms on): the clock and the
+        # busy fraction are given only for kernels that average >= 50 us per dispatch (rows with 2.7 ... 10 GHz)
+        if k in pm and pm[k].get("GRBM_GUI_ACTIVE") and t / c >= 0.05:
             cyc = pm[k]["GRBM_GUI_ACTIVE"] / 8.0
             e["mfma_busy"] = round(pm[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc), 4)
             e["clock_GHz"] = round(cyc / (pm[k]["_ms"] * 1e6), 3) if pm[k]["_ms"] else None
