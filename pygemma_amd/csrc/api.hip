@@ -170,6 +170,7 @@ extern "C" void pg_ctx_destroy(pg_ctx *ctx)
     if (ctx->tabs) (void)hipFree(ctx->tabs);
     if (ctx->stats) (void)hipFree(ctx->stats);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->plan.d_leaf) { (void)hipFree(ctx->plan.d_leaf); (void)hipFree(ctx->plan.d_node); (void)hipFree(ctx->plan.d_level); (void)hipFree(ctx->plan.d_chunk); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -266,6 +266,142 @@ __global__ __launch_bounds__(64) void chol_inv_kernel(const double *G, double *R
     for (int i = 0; i < B; i++) Rinv[i * B + lane] = (lane >= i) ? Xl[i * P65 + lane] : 0.0;
 }
 
+// ---- pass 1, blocked (r4): the same R1 and R1^-1 in ~13 us instead of 47 ----------------------------------------------------------
+// chol_inv_kernel above is 2 016 dependent (two v_readlane + FMA) steps in one wavefront, fully unrolled (~50 KB of code: beside
+// another kernel its instruction fetches alone made it 2 - 3 x slower).  Here the factorisation walks four row panels of 16 rows: ONE
+// wavefront holds the panel's 16 x 64 entries with lane = COLUMN and runs the 16 elimination steps of the panel on all columns at once
+// (120 readlane + FMA pairs per panel: the multipliers R[k][i] are wave-uniform), which yields the panel's rows of R — diagonal block and
+// everything right of it — without a separate triangular solve; the trailing blocks are updated as 16 x 16 x 16 MFMA products by all
+// four wavefronts.  1 / sqrt(pivot) from v_rsq_f64 + two Newton steps (the pivot's square root and reciprocal in ~100 cycles instead
+// of ~300).  R^-1: the four 16 x 16 diagonal inverses by one wavefront each (lane = row, coefficients by readlane), then block column K
+// by wavefront K as MFMA products: X_IK = -X_II sum_{I < M <= K} R_IM X_MK.
+__device__ __forceinline__ double rsqrt_newton(double a)
+{
+    double r = __builtin_amdgcn_rsq(a);
+    // two Newton steps r <- r (1.5 - 0.5 a r^2): quadratic from the instruction's ~2^-26 to below 2^-52
+    const double h = 0.5 * a;
+    r = fma(r, fma(-h * r, r, 0.5), r);
+    r = fma(r, fma(-h * r, r, 0.5), r);
+    return r;
+}
+// acc (16 x 16, MFMA C layout: row (lane >> 4) + 4 e, column lane & 15) += A B with A(i, k) and B(k, j) given by accessors, K = 16
+template <class FA, class FB>
+__device__ __forceinline__ void tile16_mma(doublex4 &acc, FA a, FB b, int lane)
+{
+    const int r16 = lane & 15, k4 = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a(r16, 4 * ks + k4), b(4 * ks + k4, r16), acc, 0, 0, 0);
+}
+__global__ __launch_bounds__(256) void chol_inv16_kernel(const double *G, double *R, double *Rinv, int *fail)
+{
+    extern __shared__ double lds[];      // (dynamic: 67 KB — a static allocation above 64 KB is not honoured at launch)
+    double *A = lds;                     // the matrix; its upper triangle becomes R
+    double *X = lds + MAT;               // R^-1
+    double *rinv_d = lds + 2 * MAT;      // 1 / R[j][j]
+    __shared__ int bad_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+    __builtin_amdgcn_s_setprio(3);
+    {
+        const int i = tid >> 2, j0 = (tid & 3) * 16;
+#pragma unroll
+        for (int q = 0; q < 16; q++) { A[i * P65 + j0 + q] = G[i * B + j0 + q]; X[i * P65 + j0 + q] = 0.0; }
+    }
+    if (tid == 0) bad_sh = 0;
+    __syncthreads();
+    for (int J = 0; J < 4; J++) {
+        const int o = 16 * J;
+        if (wave == 0) {
+            // rows o .. o + 15, all columns >= o: lane = column
+            double a[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) a[r] = A[(o + r) * P65 + lane];
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const double akk = readlane_d(a[k], o + k);      // (o + k is wave-uniform: v_readlane with a scalar lane select)
+                const bool bad = !(akk > 0.0) || !(akk < 1.0e300);
+                ok = ok && !bad;
+                const double inv = bad ? 1.0 : rsqrt_newton(akk), d = bad ? 1.0 : akk * inv;
+                if (lane == o + k) rinv_d[o + k] = inv;
+                const double rk = (lane > o + k) ? a[k] * inv : ((lane == o + k) ? d : 0.0);      // R[o + k][lane]
+                a[k] = rk;
+#pragma unroll
+                for (int i = k + 1; i < 16; i++) a[i] = fma(-readlane_d(rk, o + i), rk, a[i]);      // row o + i -= R[o+k][o+i] R[o+k][:]
+            }
+            if (!ok && lane == 0) bad_sh = 1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) A[(o + r) * P65 + lane] = (lane >= o + r) ? a[r] : 0.0;
+        }
+        __syncthreads();
+        // trailing blocks (I, K), J < I <= K <= 3:  A[I][K] -= R[J][I]' R[J][K]
+        {
+            int t = 0;
+            for (int I = J + 1; I < 4; I++)
+                for (int K = I; K < 4; K++, t++) {
+                    if ((t & 3) != wave) continue;
+                    doublex4 acc;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc[e] = A[(16 * I + k4 + 4 * e) * P65 + 16 * K + r16];
+                    tile16_mma(acc, [&](int i, int k) { return -A[(o + k) * P65 + 16 * I + i]; }, [&](int k, int j) { return A[(o + k) * P65 + 16 * K + j]; }, lane);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) A[(16 * I + k4 + 4 * e) * P65 + 16 * K + r16] = acc[e];
+                }
+        }
+        __syncthreads();
+    }
+    // ---- R^-1.  Diagonal blocks: wavefront J inverts R_JJ, lane = row i of X_JJ, x[j] = (delta_ij - sum_{k < j} x[k] R[k][j]) / R[j][j]
+    {
+        const int o = 16 * wave;
+        double x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            double s_ = (lane == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < j; k++) s_ = fma(-x[k], A[(o + k) * P65 + o + j], s_);      // (uniform address: an LDS broadcast)
+            x[j] = (lane <= j && lane < 16) ? s_ * rinv_d[o + j] : 0.0;
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) X[(o + lane) * P65 + o + j] = x[j];
+        }
+    }
+    __syncthreads();
+    // block column K (wavefront K), rows I = K - 1 .. 0
+    if (wave >= 1) {
+        const int K = wave;
+        for (int I = K - 1; I >= 0; I--) {
+            doublex4 sacc;
+#pragma unroll
+            for (int e = 0; e < 4; e++) sacc[e] = 0.0;
+            for (int Mb = I + 1; Mb <= K; Mb++)
+                tile16_mma(sacc, [&](int i, int k) { return A[(16 * I + i) * P65 + 16 * Mb + k]; }, [&](int k, int j) { return X[(16 * Mb + k) * P65 + 16 * K + j]; }, lane);
+            // S through LDS (X[I][K] is not in use yet), then X_IK = -X_II S
+#pragma unroll
+            for (int e = 0; e < 4; e++) X[(16 * I + k4 + 4 * e) * P65 + 16 * K + r16] = sacc[e];
+            wave_sync_lds();
+            doublex4 xa;
+#pragma unroll
+            for (int e = 0; e < 4; e++) xa[e] = 0.0;
+            tile16_mma(xa, [&](int i, int k) { return -X[(16 * I + i) * P65 + 16 * I + k]; }, [&](int k, int j) { return X[(16 * I + k) * P65 + 16 * K + j]; }, lane);
+            wave_sync_lds();
+#pragma unroll
+            for (int e = 0; e < 4; e++) X[(16 * I + k4 + 4 * e) * P65 + 16 * K + r16] = xa[e];
+            wave_sync_lds();
+        }
+    }
+    __syncthreads();
+    if (bad_sh != 0 && tid == 0) atomicOr(fail, 1);
+    {
+        const int i = tid >> 2, j0 = (tid & 3) * 16;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int c = j0 + q;
+            R[i * B + c] = (c >= i) ? A[i * P65 + c] : 0.0;
+            Rinv[i * B + c] = (c >= i) ? X[i * P65 + c] : 0.0;
+        }
+    }
+}
+
 // ---- pass 2 + Householder reconstruction ------------------------------------------------------------------------------------
 // in : G2 = Q1'Q1, R1, Q1top = first 64 rows of Q1 (ld 64)
 // out: Rs = D R2 R1 into the band block Aband (ld lda; only the upper triangle is written), V's top block (unit lower) into VW (ld 2b)
@@ -846,12 +982,13 @@ void sb2_free(Sb2Work &w)
 int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
 {
     hipStream_t st = ctx->stream;
-    constexpr int LDS4 = 4 * MAT * 8, CHOL_LDS = (2 * MAT + B) * 8;
+    constexpr int LDS4 = 4 * MAT * 8, CHOL_LDS = (2 * MAT + B) * 8, CHOL16_LDS = (2 * MAT + B) * 8;
     // the dynamic-LDS limit is a per-DEVICE property of the function: set on every call (a few microseconds, once per solve), never
     // cached per process — a second device in the same process would launch these kernels without it
     PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&recon_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
     PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
     PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CHOL_LDS));
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_inv16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CHOL16_LDS));
     PG_HIP(hipMemsetAsync(w.Vst, 0, (size_t)n * n * 8, st));
     PG_HIP(hipMemsetAsync(w.Tst, 0, (size_t)(w.npan + 1) * B * B * 8, st));
     PG_HIP(hipMemsetAsync(w.fail, 0, 4 * sizeof(int), st));
@@ -869,6 +1006,8 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
     auto VWt_of = [&](int pan_) { return VWt_base + (size_t)(pan_ & 1) * 128 * ldt; };
     double *const parts = VWt_base + (size_t)2 * 128 * ldt;
     PG_HIP(hipMemsetAsync(VWt_base, 0, (size_t)2 * 128 * ldt * 8, st));
+    bool chol16 = true;      // the blocked first-pass Cholesky (PG_SB2_CHOL16=0: the one-wavefront version)
+    if (const char *e_ = getenv("PG_SB2_CHOL16")) chol16 = atoi(e_) != 0;
     bool fused = n >= 2 * B + 2;
     if (const char *e_ = getenv("PG_SB2_FUSED")) fused = fused && atoi(e_) != 0;      // A/B timing and tests
     PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gram_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAT * 8));
@@ -894,7 +1033,8 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
             const unsigned nb = (unsigned)((m + B - 1) / B);
             panel_gram_kernel<false><<<nb, 256, 2 * MAT * 8, cs>>>(m, P, ld, nullptr, nullptr, parts);
             sum_partials_kernel<<<B * B / 32, 256, 0, cs>>>((int)nb, parts, SM(SM_G1));
-            chol_inv_kernel<<<1, 64, CHOL_LDS, cs>>>(SM(SM_G1), SM(SM_R1), SM(SM_R1INV), w.fail);
+            if (chol16) chol_inv16_kernel<<<1, 256, CHOL16_LDS, cs>>>(SM(SM_G1), SM(SM_R1), SM(SM_R1INV), w.fail);
+            else chol_inv_kernel<<<1, 64, CHOL_LDS, cs>>>(SM(SM_G1), SM(SM_R1), SM(SM_R1INV), w.fail);
             panel_gram_kernel<true><<<nb, 256, 2 * MAT * 8, cs>>>(m, P, ld, SM(SM_R1INV), Qb0, parts);
             sum_partials_kernel<<<B * B / 32, 256, 0, cs>>>((int)nb, parts, SM(SM_G2));
             recon_kernel<<<1, 256, 3 * MAT * 8, cs>>>(SM(SM_G2), SM(SM_R1), Qb0, P, ld, VW0, Vs, ld, Tp, SM(SM_XM), SM(SM_RPROD), w.fail);
@@ -932,7 +1072,11 @@ int sy2sb_device(pg_ctx *ctx, int n, double *A, Sb2Work &w)
     if (const char *e_ = getenv("PG_SB2_LOOKAHEAD")) {
         const int req = atoi(e_);
         bool ok;
-        if (req < 0) ok = hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking) == hipSuccess;       // -1: a plain second stream
+        if (req == -2) {       // -2: a second stream of the LOWEST priority: the update's workgroups yield freed slots to the panel kernels
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            ok = hipStreamCreateWithPriority(&side.stream, hipStreamNonBlocking, least) == hipSuccess;
+        } else if (req < 0) ok = hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking) == hipSuccess;       // -1: a plain second stream
         else {
             const int reserve = std::max(1, std::min(req, ctx->num_cu / 2));
             uint32_t mask[16];

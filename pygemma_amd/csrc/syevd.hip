@@ -1355,13 +1355,23 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
         sb2_free(sw);
         stedc_free(wk);
         g_arena = nullptr;
-        if (arena.base) (void)hipFree(arena.base);
+        if (arena.base && arena.base != static_cast<char *>(ctx->arena)) (void)hipFree(arena.base);      // (the context's arena stays)
         arena = DevArena{};
     };
     {   // everything below out of one allocation (when the device refuses it, the buffers are allocated one by one as before)
         const size_t nn = (size_t)n * n;
         arena.cap = sb2_bytes(n) + 8 * (2 * nn + (size_t)n * (DC_LEAF + 1) + ((size_t)n / UV_ROWS + 2) * n + 64 * (size_t)n) + ((size_t)1 << 20);
-        if (hipMalloc(reinterpret_cast<void **>(&arena.base), arena.cap) != hipSuccess) { (void)hipGetLastError(); arena = DevArena{}; }
+        constexpr size_t KEEP_MAX = (size_t)1 << 30;
+        if (arena.cap <= KEEP_MAX) {
+            // small solves take the context's arena (grown on demand, freed with the context)
+            if (ctx->arena_bytes < arena.cap) {
+                if (ctx->arena) { (void)hipStreamSynchronize(st); (void)hipFree(ctx->arena); ctx->arena = nullptr; ctx->arena_bytes = 0; }
+                if (hipMalloc(&ctx->arena, arena.cap) == hipSuccess) ctx->arena_bytes = arena.cap;
+                else { (void)hipGetLastError(); ctx->arena = nullptr; }
+            }
+            arena.base = static_cast<char *>(ctx->arena);
+            if (arena.base) arena.cap = ctx->arena_bytes; else arena = DevArena{};
+        } else if (hipMalloc(reinterpret_cast<void **>(&arena.base), arena.cap) != hipSuccess) { (void)hipGetLastError(); arena = DevArena{}; }
     }
     g_arena = &arena;
     rc = alloc_d(&A, (size_t)n * n);
