@@ -55,7 +55,7 @@ struct pg_ctx {
     pg::NpSumPlan plan;
     // generic scratch
     void *scratch = nullptr; size_t scratch_bytes = 0;
-    // the eigensolver's work arena, kept between solves while it is small (<= 1 GiB: the n ~ 2 000 class): a hipMalloc / hipFree pair
+    // the eigensolver's work arena, kept between solves up to 16 GiB (n <= ~14 000): a hipMalloc / hipFree pair
     // per solve was followed, in one solve out of three, by a kernel launch that blocked the host for 25 - 60 ms (r4, HIP API trace)
     void *arena = nullptr; size_t arena_bytes = 0;
 };

@@ -1361,7 +1361,9 @@ static int syevd_twostage(pg_ctx *ctx, int n, const float *K, float *evals, floa
     {   // everything below out of one allocation (when the device refuses it, the buffers are allocated one by one as before)
         const size_t nn = (size_t)n * n;
         arena.cap = sb2_bytes(n) + 8 * (2 * nn + (size_t)n * (DC_LEAF + 1) + ((size_t)n / UV_ROWS + 2) * n + 64 * (size_t)n) + ((size_t)1 << 20);
-        constexpr size_t KEEP_MAX = (size_t)1 << 30;
+        // kept up to 16 GiB (n <= ~14 000): on some boxes hipMalloc of the 8 GB a solve at n = 10 000 needs took 0.12 - 0.33 s, also for memory
+        // this process had just freed (profiles/r04: "allocate 329 ms"); larger arenas (200 GB at n = 50 000) are returned at once
+        constexpr size_t KEEP_MAX = (size_t)16 << 30;
         if (arena.cap <= KEEP_MAX) {
             // small solves take the context's arena (grown on demand, freed with the context)
             if (ctx->arena_bytes < arena.cap) {

@@ -5,7 +5,7 @@
 #   one pass also runs WITH the eigensolver (the library drains the stream once per panel) to show that bench.py is profilable end to end).
 # Outputs under gpurun_out/prof_${TAG}_final/ ; tools/summarize_prof.py condenses them into profiles/.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_${TAG}_final
 mkdir -p $OUT
