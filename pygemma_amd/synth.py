@@ -86,6 +86,31 @@ def fast_rotated_panel(n, p, c, seed=SEED, null=False):
     return {"d": d, "X": X, "Y": y.reshape(-1, 1), "W": W}
 
 
+def block_orthogonal(out, seed=0, blk=500):
+    """Fills the (n, n) float32 array `out` with a DENSE, orthogonal (to float32 rounding) matrix in O(n^2 blk) flops — an eigenvector
+    matrix for tests at sizes where a QR of an n x n Gaussian is out of reach (n = 50 000): U = P1 B1 P2 B2 with B1, B2 block-diagonal
+    (random orthogonal blk x blk blocks) and P1, P2 random permutations.  Every entry is a sum of ~blk^2/n products of two entries of
+    magnitude blk^-1/2, i.e. of the magnitude n^-1/2 an orthogonal matrix's entries have."""
+    n = out.shape[0]
+    assert out.shape == (n, n) and n % blk == 0
+    rng = np.random.default_rng(seed)
+    pool = [np.linalg.qr(rng.standard_normal((blk, blk)))[0].astype(np.float32) for _ in range(8)]
+    nb = n // blk
+    b1, b2 = rng.integers(0, 8, nb), rng.integers(0, 8, nb)
+    s1, s2 = rng.choice([-1.0, 1.0], n).astype(np.float32), rng.choice([-1.0, 1.0], n).astype(np.float32)
+    p1, p2 = rng.permutation(n), rng.permutation(n)
+    M = np.zeros((blk, n), np.float32)
+    for I in range(nb):
+        M[:] = 0.0
+        src = p2[I * blk:(I + 1) * blk]                      # rows of B2 that P2 brings to the rows of block I
+        for t in range(blk):
+            J, r = divmod(int(src[t]), blk)
+            M[t, J * blk:(J + 1) * blk] = pool[b2[J]][r] * s2[J * blk:(J + 1) * blk]
+        R = (pool[b1[I]] * s1[I * blk:(I + 1) * blk, None]) @ M      # signs keep the blocks orthogonal and make them distinct
+        out[p1[I * blk:(I + 1) * blk]] = R
+    return out
+
+
 def degenerate_panels(seed=0, n=203, c=3, p=16):
     """(tag, d, W, y, X) with the degeneracies a caller can hand over at the eigen-basis boundary (eigen=False passes eigenvalues
     through unclamped, lmm/lmm.py:196-207 clamps only what it computes itself): SNP columns that are zero / constant / collinear
