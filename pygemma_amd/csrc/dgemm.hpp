@@ -688,7 +688,7 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
     gp.vecB = ((uintptr_t)d.B % 16 == 0) && (d.ldb % 2 == 0) && (d.strideB % 2 == 0);
     gp.symA = (d.symA && !d.transA) ? 1 : 0;
     gp.vecC = ((uintptr_t)d.C % 16 == 0) && (d.ldc % 2 == 0) && (d.strideC % 2 == 0);
-    static const int tune_env = getenv("PG_DGEMM_TUNE") ? atoi(getenv("PG_DGEMM_TUNE")) : 0;
+    const int tune_env = getenv("PG_DGEMM_TUNE") ? atoi(getenv("PG_DGEMM_TUNE")) : 0;
     gp.tune = tune_env;
     gp.stamps = (tune_env & 8) ? g_ring_stamp_buf : nullptr;
     const bool small_m = d.M <= 64 && !d.symA, small_n = d.N <= 64 && !d.lower_only;
@@ -700,7 +700,7 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
         // at least 128 k per slice (a 64 x 64 Gram of 7400 rows: 28 slices of 264 k 26 us, 57 of 128 k 17 us; 64 k no better, 32 worse)
         ksplit = (int)std::min<long long>((768 + tiles - 1) / tiles, d.K / 128);
         if (ksplit < 2) ksplit = 1;
-        static const int ks_mode = getenv("PG_DGEMM_KSPLIT_FILL") ? atoi(getenv("PG_DGEMM_KSPLIT_FILL")) : 1;
+        const int ks_mode = getenv("PG_DGEMM_KSPLIT_FILL") ? atoi(getenv("PG_DGEMM_KSPLIT_FILL")) : 1;
         if (ks_mode && tiles >= 16) {
             // long-K shapes with many row tiles (X = A22 V): two workgroups per CU are resident, so tiles x slices should fill whole
             // rounds of 2 x CUs workgroups; among the slice counts with >= 256 k each take the best fill, the fewest slices at a tie
@@ -725,7 +725,7 @@ inline int dgemm_ex(pg_ctx *ctx, const DgemmDesc &d)
     dim3 grid((unsigned)tiles, (unsigned)ksplit, (unsigned)d.nbatch);
     hipStream_t st = ctx->stream;
     // LDS-DMA ring kernel: 128-row tiles, B k-major, 16-byte aligned operands, M >= 2 and N >= 2 (pairs are clamped, not masked)
-    static const bool ring_off = getenv("PG_DGEMM_RING") && atoi(getenv("PG_DGEMM_RING")) == 0;     // A/B timing and tests
+    const bool ring_off = getenv("PG_DGEMM_RING") && atoi(getenv("PG_DGEMM_RING")) == 0;     // A/B timing and tests (read per call: tests toggle it)
     if (!ring_off && !small_m && !d.transB && d.nbatch == 1 && gp.vecA && gp.vecB && d.M >= 2 && d.N >= 2 && d.K >= 1 && (d.kxorB % 8) == 0 &&
         (ksplit == 1 || gp.kchunk % RBK == 0)) {
         const long long tm_ = (d.M + 127) / 128, tn_ = (d.N + dbn - 1) / dbn;

@@ -1232,6 +1232,9 @@ __device__ __forceinline__ u32x4 pack2(double a, double b)
     return v;
 }
 constexpr int BC_DONE = INT_MAX / 2;
+#ifndef PG_BC_EARLY_SEND
+#define PG_BC_EARLY_SEND 1
+#endif
 // debugging aid (pgx_sb2_set_debug): a host-mapped int array the bulge-chasing kernel leaves its position in (sweep, step, phase)
 static int *g_bc_debug = nullptr;
 void sb2_set_debug(int *p) { g_bc_debug = p; }
@@ -1582,6 +1585,13 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
             double beta = alpha, tau = 0.0, scal = 0.0;
             if (xn2 != 0.0) { beta = -copysign(sqrt(alpha * alpha + xn2), alpha); tau = (beta - alpha) / beta; scal = 1.0 / (alpha - beta); }
             const double v = (lane == 0) ? 1.0 : x0 * scal;
+            // the reflector leaves for workgroup K + 1 straight from this wavefront's registers, BEFORE the barrier (r4; r3: from the last
+            // wavefront behind it): the time from the messages' arrival to this store is on the sweeps' critical cycle twice
+            if (PG_BC_EARLY_SEND && r0 + B < n) {
+                const unsigned tag = (unsigned)(s + 1);
+                __builtin_amdgcn_raw_buffer_store_b128(mb_pack(v, tag), rmail, (unsigned)(K * MB_LD * 8 + 16 * (MB_V + lane)), 0, BC_SC1);
+                if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(mb_pack(tau, tag), rmail, (unsigned)(K * MB_LD * 8 + 16 * MB_TAU), 0, BC_SC1);
+            }
             vcur[lane] = v;
             if (lane == 0) { sc[0] = tau; sc[1] = beta; TAU[(size_t)s * nk + K] = tau; }
             if (lane < L) VV[(size_t)s * n + r0 + lane] = v;
@@ -1589,8 +1599,7 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
         }
         __syncthreads();
         const double tau = sc[0];
-        // the reflector leaves for workgroup K + 1 (last wavefront; nothing waits for these stores)
-        if (wq == NW - 1 && r0 + B < n) {
+        if (!PG_BC_EARLY_SEND && wq == NW - 1 && r0 + B < n) {
             const unsigned tag = (unsigned)(s + 1);
             __builtin_amdgcn_raw_buffer_store_b128(mb_pack(vcur[lane], tag), rmail, (unsigned)(K * MB_LD * 8 + 16 * (MB_V + lane)), 0, BC_SC1);
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(mb_pack(tau, tag), rmail, (unsigned)(K * MB_LD * 8 + 16 * MB_TAU), 0, BC_SC1);

@@ -352,6 +352,24 @@ def test_stage2_back_transformation_one_block_per_trip(n, ctx, monkeypatch):
         b.free()
 
 
+@pytest.mark.parametrize("knob", ["PG_SB2_FUSED", "PG_SB2_CHOL16", "PG_DGEMM_RING", "PG_SB2_LOOKAHEAD"])
+@pytest.mark.parametrize("n", [832, 1300])
+def test_two_stage_alternative_paths(n, knob, ctx, monkeypatch):
+    """The A/B switches of round 4 keep every path alive: the panel chain as separate GEMM launches (PG_SB2_FUSED=0), the one-wavefront
+    first-pass Cholesky (PG_SB2_CHOL16=0), the register-staged GEMM kernel everywhere (PG_DGEMM_RING=0), the look-ahead of the band
+    reduction on a second stream with the thin next-panel update (PG_SB2_LOOKAHEAD=-1) — same Tier-B invariants as the default path."""
+    from pygemma_amd import ops
+    monkeypatch.setenv("PG_SYEVD_STAGES", "2")
+    monkeypatch.setenv(knob, "-1" if knob == "PG_SB2_LOOKAHEAD" else "0")
+    K = _kin(n, seed=5 * n)
+    K64 = np.tril(K.astype(np.float64)); K64 = K64 + np.tril(K64, -1).T
+    ev32, U32, ev, U = ops.syevd(K, ctx=ctx, want64=True)
+    ref = np.linalg.eigvalsh(K64)
+    assert np.abs(ev - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.abs(U.T @ U - np.eye(n)).max() <= 1e-12
+    assert np.linalg.norm(K64 - (U * ev) @ U.T) / np.linalg.norm(K64) <= 1e-12 * np.sqrt(n)
+
+
 def test_stationary_bulge_chasing_wait_expiry_falls_back_to_the_memory_kernel(ctx, monkeypatch):
     """PG_BC_TEST_FAULT=1 removes one workgroup of the stationary bulge-chasing kernel: its neighbours' bounded waits expire, the flag is
     raised (nothing hangs), and pg_syevd_dev repeats stage 2 with the kernel that carries the rows through memory — same answer."""
