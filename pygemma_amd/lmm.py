@@ -558,6 +558,7 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     t0 = time.time()
     ectx = dU0 = None  # the eigensolver's context on GPU 0 and U resident there (reused by GPU 0's SNP loop)
     xpin = pre = None
+    pin_thread, pin_box = None, {}    # page-locking of a pageable X beside the eigensolver
     comms = None
     # ONE try/finally owns every resource made from here on (prefetch contexts and threads, the page-lock of X, the communicators,
     # the eigensolver's context): whatever raises in between — a bad K, os.makedirs, the manifest, a worker — they are released
@@ -570,6 +571,17 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
                     pre = _Prefetch(L, X, blocks, n, X.dtype.itemsize, verbose)
             except _lib.PgError as ex:
                 _log(verbose, f"prefetch not started ({ex})")
+        if eigen and not packed and X.size and not _lib.is_pinned(X) and (X.flags.c_contiguous or X.flags.f_contiguous) and X.nbytes >= (256 << 20):
+            # Page-locking a pageable X in place costs ~0.06 s/GB the first time a range is registered (0.23 s for 4 GB: the kernel pins a million
+            # pages; 2 ms on a repeat) — as long as the eigensolver runs anyway, it happens beside it on a thread of its own (r4: lmm.pygemma
+            # from a pageable 4 GB X 0.77 -> ~0.5 s)
+            def _pin_bg():
+                try:
+                    pin_box["h"] = _lib.pin(X)
+                except _lib.PgError as ex:
+                    pin_box["err"] = ex
+            pin_thread = threading.Thread(target=_pin_bg, daemon=True)
+            pin_thread.start()
         if eigen:
             ectx = _lib.Context(0)
             try:
@@ -692,10 +704,16 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
                 pre.join()
                 if stats is not None:
                     stats["prefetched_bytes"] = int(pre.bytes)
-            if not packed and not _lib.is_pinned(X):
-                # page-lock the caller's X in place for the duration of the scan (hipHostRegister: ~5 ms/GB measured, tools/bench_h2d.py)
-                # so that every batch is one 2-D DMA straight out of it; if the range cannot be registered (e.g. a read-only file
-                # mapping) the workers fall back to copy threads + a pinned staging buffer
+            if pin_thread is not None:
+                pin_thread.join()
+                pin_thread = None
+                xpin = pin_box.pop("h", None)
+                if "err" in pin_box:
+                    _log(verbose, f"X could not be page-locked in place ({pin_box['err']}); staging through pinned buffers")
+            elif not packed and not _lib.is_pinned(X):
+                # page-lock the caller's X in place for the duration of the scan (hipHostRegister: 2 ms/GB for a range the kernel has pinned
+                # before, ~60 ms/GB the first time: tools/probe_pageable.py) so that every batch is one 2-D DMA straight out of it; if the
+                # range cannot be registered (e.g. a read-only file mapping) the workers fall back to copy threads + a pinned staging buffer
                 try:
                     xpin = _lib.pin(X)
                 except _lib.PgError as ex:
@@ -734,6 +752,10 @@ def pygemma(Y, X, W, K, Z=None, snps=None, verbose=0, disable_checks=True, de=Fa
     finally:
         if pre is not None:
             pre.close()
+        if pin_thread is not None:        # an exception before the loop: the registration may still be under way
+            pin_thread.join()
+            if pin_box.get("h") is not None:
+                pin_box.pop("h").close()
         if xpin is not None:
             xpin.close()
         if comms:
