@@ -184,6 +184,10 @@ def test_every_entry_point_rejects_bad_arguments_before_any_launch(ctx):
         ("pg_comm_broadcast_dev NULL comm", lambda: L.pg_comm_broadcast_dev(None, b, 16, 0)),
         ("pg_comm_init_rank rank >= nranks", lambda: L.pg_comm_init_rank(h, 2, 2, hp, C.byref(C.c_void_p()))),
         ("pg_ctx_create device out of range", lambda: L.pg_ctx_create(4096, C.byref(C.c_void_p()))),
+        ("pg_zkzt_dev q = 0", lambda: L.pg_zkzt_dev(h, n, 0, b, 0, n, b, 0, n, b, n)),
+        ("pg_zkzt_dev ldz < q", lambda: L.pg_zkzt_dev(h, n, 8, b, 0, 7, b, 0, 8, b, n)),
+        ("pg_zkzt_dev ldo < n", lambda: L.pg_zkzt_dev(h, n, 8, b, 0, 8, b, 0, 8, b, n - 1)),
+        ("pg_zkzt_dev NULL K", lambda: L.pg_zkzt_dev(h, n, 8, b, 0, 8, None, 0, 8, b, n)),
     ]
     for name, call in bad:
         rc = call()
