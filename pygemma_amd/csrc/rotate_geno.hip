@@ -29,7 +29,7 @@ namespace pg {
 // Device-side choice of the rotation path (pg_rotate_auto_dev): every candidate kernel of a block is enqueued and looks at the
 // flags the detect pass left — flag[0] bit 0: not genotype-valued, bit 1: NaN/Inf present; flag[1]: some column has an imputed
 // value — so the host never waits for them.
-enum { COND_ALWAYS = 0, COND_PASS1 = 1, COND_PASS2 = 2, COND_INDICATOR = 3, COND_SPLIT = 4, COND_FP32 = 5 };
+enum { COND_ALWAYS = 0, COND_PASS1 = 1, COND_PASS2 = 2, COND_INDICATOR = 3, COND_SPLIT = 4, COND_FP32 = 5, COND_GENO = 6 };
 __device__ __forceinline__ bool run_cond(const int *flag, int mode)
 {
     if (!flag || mode == COND_ALWAYS) return true;
@@ -39,6 +39,7 @@ __device__ __forceinline__ bool run_cond(const int *flag, int mode)
         case COND_PASS2: return !(f0 & 2) && ((f0 & 1) || f1);
         case COND_INDICATOR: return f0 == 0 && f1;
         case COND_SPLIT: return (f0 & 3) == 1;
+        case COND_GENO: return f0 == 0;
         default: return (f0 & 2) != 0;
     }
 }
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void minmax_geno_kernel(long long n, long long
     atomicMin(&kmin[g], lo);
     atomicMax(&kmax[g], hi);
 }
-template <class T>
+template <class T, bool I8 = false>      // I8: the codes as int8 0/1/2 with row stride ldk BYTES (the int8 kernel's operand), else fp16 0.0/1.0/2.0
 __global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long p, const T *X, long long ldX, const int *kmin, const int *kmax,
                                                           int *other, unsigned short *Gt, long long ldk, int *flag)
 {
@@ -176,8 +177,8 @@ __global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long
         if (i < n && g < p) {
             const float x = (float)X[i * ldX + g];
             if (x == lo) code = 0;
-            else if (x == hv) code = 0x4000;                       // fp16 2.0
-            else if (fabsf(x - mid) <= tol) code = 0x3C00;         // fp16 1.0
+            else if (x == hv) code = I8 ? 2 : 0x4000;              // fp16 2.0
+            else if (fabsf(x - mid) <= tol) code = I8 ? 1 : 0x3C00;   // fp16 1.0
             else {                                                 // the column's one other value (every occurrence the same bits)
                 const int xb = __float_as_int(x);
                 const int prev = atomicCAS(&other[g], OTHER_EMPTY, xb);
@@ -193,8 +194,10 @@ __global__ __launch_bounds__(256) void encode_geno_kernel(long long n, long long
     // thread -> two consecutive samples of one SNP row: 64 threads x 4 bytes = one 256-byte segment
     for (int r = ty; r < 64; r += 4) {
         const long long gg = g0 + r, i = i0 + 2 * tx;
-        if (gg < p && i < ldk)     // ldk is a multiple of 64: i even and i < ldk  =>  i + 1 < ldk
-            *reinterpret_cast<unsigned *>(Gt + gg * ldk + i) = (unsigned)tile[2 * tx][r] | ((unsigned)tile[2 * tx + 1][r] << 16);
+        if (gg < p && i < ldk) {   // ldk is a multiple of 64: i even and i < ldk  =>  i + 1 < ldk
+            if (I8) *reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(Gt) + gg * ldk + i) = (unsigned short)(tile[2 * tx][r] | (tile[2 * tx + 1][r] << 8));
+            else *reinterpret_cast<unsigned *>(Gt + gg * ldk + i) = (unsigned)tile[2 * tx][r] | ((unsigned)tile[2 * tx + 1][r] << 16);
+        }
     }
 }
 
@@ -248,7 +251,7 @@ __global__ void params_split_kernel(long long p, const int *kmin, const int *kma
 }
 
 // indicator plane (fp16 0/1) of the columns' other value, SNP-major like Gt; only run for blocks that have one
-template <class T>
+template <class T, bool I8 = false>      // I8: int8 0/1 with row stride ldk bytes
 __global__ __launch_bounds__(256) void indicator_geno_kernel(long long n, long long p, const T *X, long long ldX, const int *other,
                                                              unsigned short *Gi, long long ldk, const int *cond = nullptr)
 {
@@ -260,12 +263,15 @@ __global__ __launch_bounds__(256) void indicator_geno_kernel(long long n, long l
     const int ob = (g < p) ? other[g] : OTHER_EMPTY;
     for (int r = ty; r < 32; r += 8) {
         const long long i = i0 + r;
-        tile[r][tx] = (i < n && g < p && ob != OTHER_EMPTY && __float_as_int((float)X[i * ldX + g]) == ob) ? 0x3C00 : 0;
+        tile[r][tx] = (i < n && g < p && ob != OTHER_EMPTY && __float_as_int((float)X[i * ldX + g]) == ob) ? (I8 ? 1 : 0x3C00) : 0;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const long long gg = g0 + r, i = i0 + tx;
-        if (gg < p && i < ldk) Gi[gg * ldk + i] = tile[tx][r];
+        if (gg < p && i < ldk) {
+            if (I8) reinterpret_cast<signed char *>(Gi)[gg * ldk + i] = (signed char)tile[tx][r];
+            else Gi[gg * ldk + i] = tile[tx][r];
+        }
     }
 }
 __global__ void params_geno_kernel(long long p, const int *kmin, const int *kmax, const int *other, float *v0, float *dx, float *dlt)
@@ -281,8 +287,9 @@ __global__ void params_geno_kernel(long long p, const int *kmin, const int *kmax
 // 11 hom A2) -> code plane, indicator plane of the missing calls and v0 = 0, dx = 1, delta = column mean of the called
 // genotypes (what SimpleImputer(strategy='mean') puts there, experiments/benchmarks/benchmarks.py:243-244).
 // Dosage = copies of A2 (pysnptools count_A1=False, benchmarks.py:233) or of A1 (count_a1).  One workgroup per SNP.
+template <bool I8>       // I8: code and indicator planes as int8 with row stride ldk8 bytes
 __global__ __launch_bounds__(256) void decode_bed_kernel(long long n, long long p, const unsigned char *bed, long long ldb, int count_a1,
-                                                         unsigned short *Gt, unsigned short *Gi, long long ldk, float *v0, float *dx, float *dlt, int *flag)
+                                                         unsigned short *Gt, unsigned short *Gi, long long ldk, long long ldk8, float *v0, float *dx, float *dlt, int *flag)
 {
     __shared__ unsigned cnt[3];
     const long long g = blockIdx.x;
@@ -290,15 +297,17 @@ __global__ __launch_bounds__(256) void decode_bed_kernel(long long n, long long 
     if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
     __syncthreads();
     unsigned n1 = 0, n2 = 0, nm = 0;
-    for (long long i = threadIdx.x; i < ldk; i += blockDim.x) {
+    const long long span = I8 ? ldk8 : ldk;
+    for (long long i = threadIdx.x; i < span; i += blockDim.x) {
         unsigned short code = 0, ind = 0;
         if (i < n) {
             const unsigned c = (row[i >> 2] >> (2 * (i & 3))) & 3u;
-            if (c == 1u) { ind = 0x3C00; nm++; }
-            else if (c == 2u) { code = 0x3C00; n1++; }
-            else if ((c == 3u) != (count_a1 != 0)) { code = 0x4000; n2++; }     // hom A2 counts 2 (A2 dosage) / hom A1 counts 2 (A1 dosage)
+            if (c == 1u) { ind = I8 ? 1 : 0x3C00; nm++; }
+            else if (c == 2u) { code = I8 ? 1 : 0x3C00; n1++; }
+            else if ((c == 3u) != (count_a1 != 0)) { code = I8 ? 2 : 0x4000; n2++; }     // hom A2 counts 2 (A2 dosage) / hom A1 counts 2 (A1 dosage)
         }
-        Gt[g * ldk + i] = code; Gi[g * ldk + i] = ind;
+        if (I8) { reinterpret_cast<signed char *>(Gt)[g * ldk8 + i] = (signed char)code; reinterpret_cast<signed char *>(Gi)[g * ldk8 + i] = (signed char)ind; }
+        else { Gt[g * ldk + i] = code; Gi[g * ldk + i] = ind; }
     }
     atomicAdd(&cnt[0], n1); atomicAdd(&cnt[1], n2); atomicAdd(&cnt[2], nm);   // integer sums: order-independent
     __syncthreads();
@@ -576,46 +585,353 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same rotation on the int8 matrix pipe (r4): genotype CODES only (path (1) above and .bed blocks; indicator and split-plane
+// passes stay on fp16).  v_mfma_i32_16x16x64_i8 takes the cycles of v_mfma_f32_16x16x32_f16 for twice the K
+// (profiles/r03_mfma_sustained.txt: 2 620 TOP/s sustained against 1 285 TF), the codes 0/1/2 are exact in int8 and the integer
+// accumulation is EXACT, so all of the error sits in the representation of U:
+//     U[i][k] = 2^(E_k - 22) * (q_ik + e),  q_ik = rint(U[i][k] * 2^(22 - E_k)) = 65536 d2 + 256 d1 + d0,  d in [-128, 127],  |e| <= 1/2
+// a 24-bit fixed point per EIGENVECTOR (2^E_k = the power of two at or below max_i |U[i][k]|, one higher when the top digit would
+// overflow): |error of U[i][k]| <= 2^-24 * 2^(E_k+1) — float32's own rounding for entries within a factor two of the column's largest,
+// k bits coarser for entries 2^-k below it.  For delocalised eigenvectors (entries ~ N(0, 1/n), maximum ~ 5 sigma) the error of U'x is
+// ~ 0.5x what the fp32 accumulation of the fp16 kernel (and of the reference's sgemm) carries; tools/geno_accuracy.py measures both.
+// Three planes = three GEMM passes where fp16 x 2 needs two at half the rate: 0.75 of the MFMA work.
+//
+// The planes cannot share an accumulator (different weights) and three accumulator sets do not fit the registers, so the planes are
+// laid out as OUTPUT COLUMNS: the plane matrix Up8 has 256 rows per tile of 85 eigen indices — rows [0, 85) digit d2, [85, 170) d1,
+// [170, 255) d0, row 255 zero — and the kernel is a plain 256 x 256 int8 GEMM tile over K-tiles of 128 samples (128-byte rows: the
+// LDS image, swizzle, DMA shapes and fragment reads are byte-for-byte those of the fp16 kernel).  The three digits of an output meet
+// in the epilogue, through the LDS the main loop has released: i32 accumulators -> LDS, then per output 65536 a2 + 256 a1 + a0 in
+// fp64 (exact), times dx_g * 2^(E_k - 22), plus v0_g * (U'1)_k, one rounding to float32 — and row-contiguous 340-byte stores.
+// Every stage now brings a new genotype tile (no second plane to reuse it for): the early waves stage the whole 32 KB tile of stage
+// s+1 during stage s (8 DMA instructions per wave, waited at the END of their MFMA phase), into the buffer whose last readers — the
+// late waves' memory phase of stage s-1 — finished one barrier earlier.
+typedef int intx4 __attribute__((ext_vector_type(4)));
+constexpr int GBK8 = 128;      // samples per K-tile (int8): 128-byte rows again
+constexpr int I8_EIG = 85;     // eigen indices per 256-row tile of the plane matrix (3 x 85 = 255)
+
+struct GenoI8Params {
+    long long n, p, ldx, ldk8;
+    const signed char *Gt8, *Up8;
+    const float *v0, *dx;            // v0 == nullptr: the accumulate pass (Xr += dx * U'plane)
+    const double *colsum, *wscale;   // wscale[k] = 2^(E_k - 22)
+    float *Xr;
+    int tiles_m, tiles_n, KT;
+    const int *cond;
+    int cmode;
+};
+
+__global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
+{
+    if (!run_cond(gp.cond, gp.cmode)) return;
+    constexpr int TBUF = 256 * 128;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char *const Bs = lds, *const As = lds + 3 * TBUF;
+    const int T = gp.tiles_m * gp.tiles_n;
+    const int b = blockIdx.x;
+    const int q = T / 8, r = T % 8, xcd = b % 8;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    const int per_group = PG_GENO_GRP * gp.tiles_n;
+    const int grp = lid / per_group, first_m = grp * PG_GENO_GRP;
+    const int gsz = (gp.tiles_m - first_m) < PG_GENO_GRP ? (gp.tiles_m - first_m) : PG_GENO_GRP;
+    const int tm = first_m + (lid % per_group) % gsz, tn = (lid % per_group) / gsz;
+    const long long m0 = (long long)tm * 256, r0 = (long long)tn * 256, k0 = (long long)tn * I8_EIG;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves, each 64 (SNPs) x 128 (plane rows)
+
+    intx4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[i][j][e] = 0;
+
+    const bool late = wave >= 4;
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    const unsigned char *gsrc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int row = (wave & 3) * 64 + 8 * t + lrow;
+        long long rm = m0 + row;
+        rm = rm < gp.p ? rm : gp.p - 1;
+        gsrc[t] = (late ? reinterpret_cast<const unsigned char *>(gp.Up8 + (r0 + row) * gp.ldk8)      // the plane matrix is padded to whole tiles
+                        : reinterpret_cast<const unsigned char *>(gp.Gt8 + rm * gp.ldk8)) + swz(row, lchunk) * 16;
+    }
+    auto dmaB = [&](int stage, int buf) {            // late waves only
+        unsigned char *dst = Bs + buf * TBUF + ((wave & 3) * 64) * 128;
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[t] + (size_t)stage * GBK8),
+                                             (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
+    };
+    auto dmaA = [&](int stage) {                     // early waves only: the wave's 64 rows of the genotype tile
+        unsigned char *dst = As + (stage & 1) * TBUF + ((wave & 3) * 64) * 128;
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[t] + (size_t)stage * GBK8),
+                                             (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
+    };
+    if (late) {
+        dmaB(0, 0);
+        if (gp.KT > 1) { dmaB(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        dmaA(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();
+    int b0 = 0;
+    const int chunk0 = lane >> 4;
+    for (int kt = 0; kt < gp.KT; kt++) {
+        const unsigned char *Acur = As + (kt & 1) * TBUF;
+        const unsigned char *Bcur = Bs + b0 * TBUF;
+        const int b2 = (b0 >= 1) ? b0 - 1 : 2;            // (kt + 2) % 3
+        bool issued = false;
+        // ---------------- memory phase
+        if (late) { if (kt + 2 < gp.KT) { dmaB(kt + 2, b2); issued = true; } }
+        else if (kt + 1 < gp.KT) dmaA(kt + 1);
+        intx4 fa[2][4], fb[8];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = wm * 64 + i * 16 + (lane & 15);
+                fa[ks][i] = *reinterpret_cast<const intx4 *>(Acur + row * 128 + swz(row, 4 * ks + chunk0) * 16);
+            }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int row = wn * 128 + j * 16 + (lane & 15);
+            fb[j] = *reinterpret_cast<const intx4 *>(Bcur + row * 128 + swz(row, chunk0) * 16);
+        }
+        if (late) {         // everything this wave issued before this stage has landed
+            if (issued) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- MFMA phase
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[0][i], fb[j], acc[i][j], 0, 0, 0);
+            const int row = wn * 128 + j * 16 + (lane & 15);
+            fb[j] = *reinterpret_cast<const intx4 *>(Bcur + row * 128 + swz(row, 4 + chunk0) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[1][i], fb[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the genotype tile of the next stage is in LDS
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        b0 = (b0 == 2) ? 0 : b0 + 1;
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+    // ---------------- epilogue: the three digits of each output meet through LDS (all staging buffers are free now)
+    const bool accum = gp.v0 == nullptr;           // the indicator pass: Xr += delta_g * U'ind_g
+    constexpr int LDW = 260;                       // words per staged row: the 4 row groups of a store (rows 4 apart) x 16 columns fall on 64 different banks
+    int *const stg = reinterpret_cast<int *>(lds);
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        if ((wm >> 1) == half) {
+            const int rb = (wm & 1) * 64;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        stg[(rb + i * 16 + 4 * (lane >> 4) + e) * LDW + wn * 128 + j * 16 + (lane & 15)] = acc[i][j][e];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 128 * I8_EIG; idx += 512) {
+            const int rr = idx / I8_EIG, ee = idx - rr * I8_EIG;
+            const long long row = m0 + half * 128 + rr, col = k0 + ee;
+            if (row < gp.p && col < gp.n) {
+                const int *s = stg + rr * LDW + ee;
+                const double P = (double)s[0] * 65536.0 + (double)s[I8_EIG] * 256.0 + (double)s[2 * I8_EIG];     // exact
+                float *dst = gp.Xr + row * gp.ldx + col;
+                const double base = accum ? (double)(*dst) : (double)gp.v0[row] * gp.colsum[col];
+                *dst = (float)fma((double)gp.dx[row] * gp.wscale[col], P, base);
+            }
+        }
+        __syncthreads();
+    }
+    if (tn == gp.tiles_n - 1) {                    // the pad columns [n, ldx) of the rotated rows are zero (the association kernel reads whole rows)
+        const int padw = (int)(gp.ldx - gp.n);
+        for (int idx = tid; idx < 256 * padw; idx += 512) {
+            const long long row = m0 + idx / padw;
+            if (row < gp.p) gp.Xr[row * gp.ldx + gp.n + idx % padw] = 0.0f;
+        }
+    }
+}
+
+// per-eigenvector exponent and the three int8 digit planes of U (see rotate_geno_i8_kernel)
+__global__ __launch_bounds__(256) void colmax_kernel(long long n, long long ldU, const float *U, int *key)
+{
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long k = (long long)blockIdx.x * 64 + tx, i0 = (long long)blockIdx.y * 256;
+    if (k >= n) return;
+    int m = 0;
+    for (long long i = i0 + ty; i < i0 + 256 && i < n; i += 4) {
+        const int bts = __float_as_int(U[i * ldU + k]) & 0x7FFFFFFF;
+        m = bts > m ? bts : m;
+    }
+    atomicMax(&key[k], m);
+}
+__global__ void i8_scale_kernel(long long n, const int *key, float *qscale, double *wscale)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float mx = __int_as_float(key[k]);
+    int E = ((key[k] >> 23) & 0xFF) - 127;                 // floor(log2 max); NaN / Inf never reach the int8 path (block flags)
+    if (!(mx > 0.0f) || E < -100) { qscale[k] = 1.0f; wscale[k] = 1.0; return; }     // an all-zero (or vanishing) column: q = 0
+    if (ldexpf(mx, 22 - E) > 8355711.0f) E++;              // 127 * 65536 + 127 * 256 + 127: the top digit must stay <= 127
+    qscale[k] = ldexpf(1.0f, 22 - E);
+    wscale[k] = ldexp(1.0, E - 22);
+}
+__global__ __launch_bounds__(256) void split_u_i8_kernel(long long n, long long ldU, const float *U, signed char *Up8, long long ldk8, const float *qscale)
+{
+    __shared__ float tile[64][65];
+    const long long k0 = (long long)blockIdx.x * 64, i0 = (long long)blockIdx.y * 64;   // eigen index block, sample block
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const long long i = i0 + r, k = k0 + tx;
+        tile[r][tx] = (i < n && k < n) ? U[i * ldU + k] : 0.0f;
+    }
+    __syncthreads();
+    if (i0 + tx >= ldk8) return;
+    for (int r = ty; r < 64; r += 4) {      // r: eigen index within the block, tx: sample
+        const long long k = k0 + r;
+        if (k >= n) continue;
+        const int qv = (int)rintf(tile[tx][r] * qscale[k]);          // the product is exact (power of two), |q| <= 127.5 * 65536
+        const int d0 = ((qv + 128) & 255) - 128, q1 = (qv - d0) >> 8;
+        const int d1 = ((q1 + 128) & 255) - 128, d2 = (q1 - d1) >> 8;
+        signed char *dst = Up8 + ((k / I8_EIG) * 256 + k % I8_EIG) * ldk8 + i0 + tx;
+        dst[0] = (signed char)d2; dst[(long long)I8_EIG * ldk8] = (signed char)d1; dst[(long long)2 * I8_EIG * ldk8] = (signed char)d0;
+    }
+}
 }  // namespace pg
 
 using namespace pg;
 
-// Prepare U once per eigendecomposition: two fp16 planes of S*U + fp64 column sums + {S, 1/S}.  Uprep must hold pg_geno_prep_bytes(n) bytes.
+// Layout of the prepared U (one allocation of pg_geno_prep_bytes(n) bytes): fp16 planes | per-K-tile and final fp64 column sums |
+// {S, 1/S} + max|U| key | int8 digit planes (whole 256-row tiles of 85 eigen indices) | 2^(E_k - 22) fp64 | 2^(22 - E_k) fp32 | max keys
+struct PrepLayout {
+    long long kt, ldp, kt8, ldk8, tiles8;
+    size_t sums, scale, planes8, wscale, qscale, keys, total;
+};
+static PrepLayout prep_layout(long long n)
+{
+    PrepLayout L;
+    L.kt = (n + GBK - 1) / GBK; L.ldp = L.kt * 2 * GBK;
+    L.kt8 = (n + GBK8 - 1) / GBK8; L.ldk8 = L.kt8 * GBK8;
+    L.tiles8 = (n + I8_EIG - 1) / I8_EIG;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    L.sums = up((size_t)n * L.ldp * 2);
+    L.scale = L.sums + (size_t)(L.kt + 1) * n * 8;
+    L.planes8 = up(L.scale + 256);
+    L.wscale = up(L.planes8 + (size_t)L.tiles8 * 256 * L.ldk8);
+    L.qscale = up(L.wscale + (size_t)n * 8);
+    L.keys = up(L.qscale + (size_t)n * 4);
+    L.total = up(L.keys + (size_t)n * 4);
+    return L;
+}
+// PG_GENO_I8=0 keeps genotype codes on the fp16 x 2 kernel (A/B, tests); read per call
+static bool geno_i8_enabled()
+{
+    const char *e = getenv("PG_GENO_I8");
+    return !(e && atoi(e) == 0);
+}
+
+// Prepare U once per eigendecomposition: two fp16 planes of S*U + fp64 column sums + {S, 1/S}, and the three int8 digit planes with
+// their per-eigenvector scales.  Uprep must hold pg_geno_prep_bytes(n) bytes.
 extern "C" size_t pg_geno_prep_bytes(int64_t n)
 {
-    const long long kt = (n + GBK - 1) / GBK;
-    const size_t planes = (size_t)n * kt * 2 * GBK * 2;
-    const size_t sums = (size_t)(kt + 1) * n * 8;
-    return ((planes + 255) & ~(size_t)255) + sums + 256;   // tail: {S, 1/S} floats + the max|U| key
+    return prep_layout(n).total;
 }
 extern "C" int pg_geno_prep_dev(pg_ctx *ctx, int64_t n, const float *U, int64_t ldU, void *Uprep)
 {
     PG_REQUIRE(ctx && U && Uprep && n > 0 && ldU >= n, "pg_geno_prep_dev: bad arguments");
     PG_HIP(hipSetDevice(ctx->device));
-    const long long kt = (n + GBK - 1) / GBK, ldp = kt * 2 * GBK;
+    const PrepLayout L = prep_layout(n);
+    const long long kt = L.kt, ldp = L.ldp;
     unsigned short *Up = (unsigned short *)Uprep;
-    double *colsum = (double *)((char *)Uprep + (((size_t)n * ldp * 2 + 255) & ~(size_t)255));
-    float *scale = (float *)(colsum + (size_t)(kt + 1) * n);
+    double *colsum = (double *)((char *)Uprep + L.sums);
+    float *scale = (float *)((char *)Uprep + L.scale);
     int *key = (int *)(scale + 2);
     PG_HIP(hipMemsetAsync(key, 0, 4, ctx->stream));
     absmax_kernel<<<1024, 256, 0, ctx->stream>>>(n, ldU, U, key);
     scale_kernel<<<1, 1, 0, ctx->stream>>>(key, scale);
     split_u_kernel<<<dim3((unsigned)((n + 63) / 64), (unsigned)kt), 256, 0, ctx->stream>>>(n, ldU, U, Up, ldp, colsum, scale);
     colsum_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(n, (int)kt, colsum);
+    // int8 digit planes: pad rows (row 255 of every tile, eigen indices past n) and pad samples stay zero
+    signed char *Up8 = (signed char *)Uprep + L.planes8;
+    double *wscale = (double *)((char *)Uprep + L.wscale);
+    float *qscale = (float *)((char *)Uprep + L.qscale);
+    int *keys = (int *)((char *)Uprep + L.keys);
+    PG_HIP(hipMemsetAsync(Up8, 0, (size_t)L.tiles8 * 256 * L.ldk8, ctx->stream));
+    PG_HIP(hipMemsetAsync(keys, 0, (size_t)n * 4, ctx->stream));
+    colmax_kernel<<<dim3((unsigned)((n + 63) / 64), (unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(n, ldU, U, keys);
+    i8_scale_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(n, keys, qscale, wscale);
+    split_u_i8_kernel<<<dim3((unsigned)((n + 63) / 64), (unsigned)((L.ldk8 + 63) / 64)), 256, 0, ctx->stream>>>(n, ldU, U, Up8, L.ldk8, qscale);
     PG_HIP(hipGetLastError());
     return PG_OK;
 }
 
-static int launch_geno_gemm(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const unsigned short *Gt, const unsigned short *Gi,
-                            const float *v0, const float *dx, const float *dlt, float *Xr, int64_t ldx, bool second_pass, const int *cond = nullptr)
+// Pass 1 on the int8 kernel (Gt holds int8 codes, row stride ldk8 bytes)
+static int launch_geno_i8(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const void *Gt8, const float *v0, const float *dx, float *Xr,
+                          int64_t ldx, const int *cond, int cmode)
 {
-    const long long kt = (n + GBK - 1) / GBK, ldk = kt * GBK, ldp = kt * 2 * GBK;
+    const PrepLayout L = prep_layout(n);
+    GenoI8Params gp{};
+    gp.n = n; gp.p = p; gp.ldx = ldx; gp.ldk8 = L.ldk8;
+    gp.Gt8 = (const signed char *)Gt8; gp.Up8 = (const signed char *)Uprep + L.planes8;
+    gp.colsum = (const double *)((const char *)Uprep + L.sums) + (size_t)L.kt * n;
+    gp.wscale = (const double *)((const char *)Uprep + L.wscale);
+    gp.v0 = v0; gp.dx = dx; gp.Xr = Xr;
+    gp.tiles_m = (int)((p + 255) / 256); gp.tiles_n = (int)L.tiles8; gp.KT = (int)L.kt8;
+    const long long T = (long long)gp.tiles_m * gp.tiles_n;
+    PG_REQUIRE(T < (1LL << 31), "genotype rotation: too many tiles");
+    constexpr int WLDS = 5 * 256 * 128;
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rotate_geno_i8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
+    gp.cond = cond; gp.cmode = cond ? cmode : COND_ALWAYS;
+    rotate_geno_i8_kernel<<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
+    PG_HIP(hipGetLastError());
+    return PG_OK;
+}
+
+// i8codes: Gt / Gi hold int8 genotype codes / indicators for the int8 kernel (the caller encoded them that way: geno_i8_enabled());
+// with block flags (cond) the fp16 kernel still takes both passes of a split-plane block, whose planes have overwritten Gt and Gi.
+static int launch_geno_gemm(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const unsigned short *Gt, const unsigned short *Gi,
+                            const float *v0, const float *dx, const float *dlt, float *Xr, int64_t ldx, bool second_pass, const int *cond = nullptr,
+                            bool i8codes = false)
+{
+    const PrepLayout L = prep_layout(n);
+    const long long kt = L.kt, ldk = kt * GBK, ldp = L.ldp;
+    if (i8codes) {      // genotype block: codes, then (if any column holds an imputed value) the indicator plane, both int8
+        int rc = launch_geno_i8(ctx, n, p, Uprep, Gt, v0, dx, Xr, ldx, cond, COND_GENO);
+        if (rc) return rc;
+        if (second_pass) {
+            rc = launch_geno_i8(ctx, n, p, Uprep, Gi, nullptr, dlt, Xr, ldx, cond, COND_INDICATOR);
+            if (rc) return rc;
+        }
+        if (!cond) return PG_OK;
+    }
     GenoParams gp{};
     gp.n = n; gp.p = p; gp.ldx = ldx; gp.ldk = ldk; gp.ldp = ldp;
     gp.Gt = Gt; gp.Up = (const unsigned short *)Uprep;
-    const double *sums = (const double *)((const char *)Uprep + (((size_t)n * ldp * 2 + 255) & ~(size_t)255));
+    const double *sums = (const double *)((const char *)Uprep + L.sums);
     gp.colsum = sums + (size_t)kt * n;
-    gp.scale = (const float *)(sums + (size_t)(kt + 1) * n);
+    gp.scale = (const float *)((const char *)Uprep + L.scale);
     gp.v0 = v0; gp.dx = dx; gp.Xr = Xr;
     constexpr int WLDS = 5 * 256 * 128;
     // per device (the attribute belongs to the function object of the current device; contexts of several GPUs share this process)
@@ -630,11 +946,11 @@ static int launch_geno_gemm(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep
     gp.tiles_m = (int)((p + 255) / 256); gp.tiles_n = (int)((n + 255) / 256); gp.KT = (int)kt;
     const long long T = (long long)gp.tiles_m * gp.tiles_n;
     PG_REQUIRE(T < (1LL << 31), "genotype rotation: too many tiles");
-    gp.cond = cond; gp.cmode = cond ? COND_PASS1 : COND_ALWAYS;
+    gp.cond = cond; gp.cmode = cond ? (i8codes ? COND_SPLIT : COND_PASS1) : COND_ALWAYS;
     if (mf16) rotate_geno_kernel<16><<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
     else rotate_geno_kernel<32><<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
-    if (second_pass) {   // Xr += delta * U'ind
-        gp.Gt = Gi; gp.v0 = nullptr; gp.dx = dlt; gp.cmode = cond ? COND_PASS2 : COND_ALWAYS;
+    if (second_pass) {   // Xr += delta * U'ind (or the second plane of a split block)
+        gp.Gt = Gi; gp.v0 = nullptr; gp.dx = dlt; gp.cmode = cond ? (i8codes ? COND_SPLIT : COND_PASS2) : COND_ALWAYS;
         if (mf16) rotate_geno_kernel<16><<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
         else rotate_geno_kernel<32><<<dim3((unsigned)T), 512, WLDS, ctx->stream>>>(gp);
     }
@@ -666,7 +982,10 @@ static int rotate_geno_any(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep,
     PG_HIP(hipMemsetAsync(flag, 0, 8, ctx->stream));
     minmax_init_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, other);
     minmax_geno_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, flag);
-    encode_geno_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((ldk + 127) / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk, flag);
+    const bool i8 = geno_i8_enabled();
+    const long long ldk8 = prep_layout(n).ldk8;
+    if (i8) encode_geno_kernel<T, true><<<dim3((unsigned)((p + 63) / 64), (unsigned)(ldk8 / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk8, flag);
+    else encode_geno_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((ldk + 127) / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk, flag);
     params_geno_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, other, v0, dx, dlt);
     PG_HIP(hipGetLastError());
     int hflag[2] = {0, 0};
@@ -681,9 +1000,11 @@ static int rotate_geno_any(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep,
         return launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, true);
     }
     *is_geno_host = 1;
-    if (hflag[1])
-        indicator_geno_kernel<T><<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk);
-    return launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, hflag[1] != 0);
+    if (hflag[1]) {
+        if (i8) indicator_geno_kernel<T, true><<<dim3((unsigned)((p + 31) / 32), (unsigned)(ldk8 / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk8);
+        else indicator_geno_kernel<T><<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk);
+    }
+    return launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, hflag[1] != 0, nullptr, i8);
 }
 
 extern "C" int pg_rotate_geno_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, const float *X, int64_t ldX, float *Xr, int64_t ldx,
@@ -725,14 +1046,18 @@ static int rotate_auto_any(pg_ctx *ctx, int64_t n, int64_t p, const float *U, in
     PG_HIP(hipMemsetAsync(flag, 0, 8, ctx->stream));
     minmax_init_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, other);
     minmax_geno_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((n + 255) / 256)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, flag);
-    encode_geno_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((ldk + 127) / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk, flag);
+    const bool i8 = geno_i8_enabled();
+    const long long ldk8 = prep_layout(n).ldk8;
+    if (i8) encode_geno_kernel<T, true><<<dim3((unsigned)((p + 63) / 64), (unsigned)(ldk8 / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk8, flag);
+    else encode_geno_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((ldk + 127) / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, other, Gt, ldk, flag);
     params_geno_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, other, v0, dx, dlt);
     // genotype block with an imputed value: indicator plane; finite non-genotype block: X in two fp16 planes (overwrites Gt, Gi, params)
-    indicator_geno_kernel<T><<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk, flag);
+    if (i8) indicator_geno_kernel<T, true><<<dim3((unsigned)((p + 31) / 32), (unsigned)(ldk8 / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk8, flag);
+    else indicator_geno_kernel<T><<<dim3((unsigned)((p + 31) / 32), (unsigned)((ldk + 31) / 32)), 256, 0, ctx->stream>>>(n, p, X, ldX, other, Gi, ldk, flag);
     split_x_kernel<T><<<dim3((unsigned)((p + 63) / 64), (unsigned)((ldk + 127) / 128)), 256, 0, ctx->stream>>>(n, p, X, ldX, kmin, kmax, Gt, Gi, ldk, flag);
     params_split_kernel<<<(unsigned)((p + 255) / 256), 256, 0, ctx->stream>>>(p, kmin, kmax, v0, dx, dlt, flag);
     PG_HIP(hipGetLastError());
-    int rc = launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, true, flag);
+    int rc = launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, true, flag, i8);
     if (rc) return rc;
     if constexpr (std::is_same<T, float>::value) {       // NaN / Inf block (float input only): the reference's propagation
         PG_REQUIRE(U && ldU >= n, "pg_rotate_auto_dev: U is needed for the fp32 fallback");
@@ -811,10 +1136,13 @@ extern "C" int pg_rotate_bed_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *
     float *v0 = (float *)tail, *dx = v0 + p, *dlt = dx + p;
     int *flag = (int *)(dlt + p) + 3 * p;
     PG_HIP(hipMemsetAsync(flag, 0, 8, ctx->stream));
-    decode_bed_kernel<<<(unsigned)p, 256, 0, ctx->stream>>>(n, p, bed, ldb, count_a1, Gt, Gi, ldk, v0, dx, dlt, flag);
+    const bool i8 = geno_i8_enabled();
+    const long long ldk8 = prep_layout(n).ldk8;
+    if (i8) decode_bed_kernel<true><<<(unsigned)p, 256, 0, ctx->stream>>>(n, p, bed, ldb, count_a1, Gt, Gi, ldk, ldk8, v0, dx, dlt, flag);
+    else decode_bed_kernel<false><<<(unsigned)p, 256, 0, ctx->stream>>>(n, p, bed, ldb, count_a1, Gt, Gi, ldk, ldk8, v0, dx, dlt, flag);
     PG_HIP(hipGetLastError());
     int hflag[2] = {0, 0};
     PG_HIP(hipMemcpyAsync(hflag, flag, 8, hipMemcpyDeviceToHost, ctx->stream));
     PG_HIP(hipStreamSynchronize(ctx->stream));
-    return launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, hflag[1] != 0);
+    return launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, hflag[1] != 0, nullptr, i8);
 }

@@ -41,13 +41,19 @@ def _geno(rng, n, p, standardise):
     return G.astype(np.float32)
 
 
-@pytest.mark.parametrize("mfma", [16, 32])
+def _kernel_env(monkeypatch, kern):
+    """the three kernels a genotype block can take: int8 digit planes (shipped), fp16 x 2 on 16 x 16 x 32 (PG_GENO_I8=0: the kernel of
+    split-plane blocks, and the r2-r3 genotype kernel), its 32 x 32 x 16 instantiation (PG_GENO_MFMA=32: measured alternative, slower)"""
+    monkeypatch.setenv("PG_GENO_I8", "1" if kern == "i8" else "0")
+    monkeypatch.setenv("PG_GENO_MFMA", "32" if kern == "f16_32x32" else "16")
+
+
+@pytest.mark.parametrize("kern", ["i8", "f16", "f16_32x32"])
 @pytest.mark.parametrize("n,p,std", [(64, 32, True), (257, 130, True), (300, 128, False), (1000, 516, True), (2000, 200, True)])
-def test_rotate_genotype_fast_path(n, p, std, mfma, ctx, monkeypatch):
-    """fp16x2 genotype path: error vs the fp64 rotation within the fp32-GEMM class (and no worse than the fp32-MFMA path) — the
-    shipped kernel on v_mfma_f32_16x16x32_f16 and its 32 x 32 x 16 instantiation (PG_GENO_MFMA=32: measured alternative, slower)."""
+def test_rotate_genotype_fast_path(n, p, std, kern, ctx, monkeypatch):
+    """genotype path: error vs the fp64 rotation within the fp32-GEMM class (and no worse than the fp32-MFMA path), on each of its kernels."""
     from pygemma_amd import ops
-    monkeypatch.setenv("PG_GENO_MFMA", str(mfma))
+    _kernel_env(monkeypatch, kern)
     rng = np.random.default_rng(n + p)
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
     U = Q.astype(np.float32)
@@ -62,6 +68,51 @@ def test_rotate_genotype_fast_path(n, p, std, mfma, ctx, monkeypatch):
     err_f = np.abs(f32p - exact) / bound
     assert err_g.max() <= 4 * 2.0 ** -24 * np.sqrt(n) and np.median(err_g) <= 2 * max(np.median(err_f), 1e-9)
     assert (got[:, n:] == 0).all()
+
+
+@pytest.mark.parametrize("kind", ["blocks", "twins", "graded", "identity"])
+def test_rotate_int8_planes_with_localised_eigenvectors(kind, ctx, monkeypatch):
+    """The int8 kernel holds U as a 24-bit fixed point per EIGENVECTOR (scale = that column's largest entry), so entries far below the
+    column's maximum are coarser than in float32.  Eigenvectors of structured K are like that: block-diagonal K (families: each vector
+    lives on one block), duplicated samples (twins: (1, -1)/sqrt 2 and zeros), entries graded over many decades, and U = I.  The error
+    against the fp64 rotation must stay within the representation's own worst case, and in norm per SNP row no worse than 3x the
+    fp32-MFMA kernel (the reference's sgemm class)."""
+    from pygemma_amd import ops
+    monkeypatch.setenv("PG_GENO_I8", "1")
+    rng = np.random.default_rng(11)
+    n, p = 900, 300
+    if kind == "blocks":
+        U = np.zeros((n, n))
+        at = 0
+        for b in [2, 3, 5, 40, 150, 700]:
+            U[at:at + b, at:at + b] = np.linalg.qr(rng.standard_normal((b, b)))[0]; at += b
+        U = U[rng.permutation(n)][:, rng.permutation(n)]
+    elif kind == "twins":
+        U = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        U[:, 0] = 0; U[3, 0] = 2 ** -0.5; U[8, 0] = -2 ** -0.5
+        U[:, 1] = 1e-5 * rng.standard_normal(n); U[5, 1] = 1.0            # one dominant entry over a floor 5 decades down
+    elif kind == "graded":
+        U = np.linalg.qr(rng.standard_normal((n, n)))[0] * (10.0 ** rng.uniform(-6, 0, (n, 1)))     # sample rows graded over 6 decades
+    else:
+        U = np.eye(n)
+    U = U.astype(np.float32)
+    X = _geno(rng, n, p, kind != "identity")
+    got, ok = ops.rotate_geno(U, X, ctx=ctx)
+    assert ok == 1
+    exact = (U.astype(np.float64).T @ X.astype(np.float64)).T
+    f32p = ops.rotate(U, X, ctx=ctx)[:, :n]
+    A = np.abs(U.astype(np.float64))
+    worst = np.abs(X.astype(np.float64)).sum(0)[:, None] * A.max(0)[None, :]               # sum_i |x_i| max_i |u_ik|
+    enc = 16 * 2.0 ** -24 * np.abs(X).max(0).astype(np.float64)[:, None] * A.sum(0)[None, :]   # x = v0 + dx * code holds to 8 ulp of the column's largest value
+    err = np.abs(got[:, :n] - exact)
+    assert (err <= 2.0 ** -23 * worst + 2.0 ** -23 * np.abs(exact) + enc).all()            # the representation's worst case + the output rounding
+    rown = lambda a: np.sqrt((a ** 2).sum(1))
+    # measured: 0.3 - 0.6x the fp32-MFMA kernel's error on blocks / twins, 1.3 - 1.5x on the graded rows (6 decades inside every vector)
+    assert (rown(err) <= 3 * rown(f32p - exact) + 2.0 ** -24 * rown(exact)).all()
+    print(kind, "row-norm error / fp32-MFMA kernel's:", float(np.median(rown(err) / np.maximum(rown(f32p - exact), 1e-300))))
+    assert (got[:, n:] == 0).all()
+    if kind == "identity":
+        assert (got[:, :n] == X.T).all()
 
 
 def test_rotate_non_genotype_block_split_path_and_nan_rejection(ctx):
@@ -89,11 +140,13 @@ def test_rotate_non_genotype_block_split_path_and_nan_rejection(ctx):
     assert ok == 0 and got is None
 
 
+@pytest.mark.parametrize("kern", ["i8", "f16"])
 @pytest.mark.parametrize("n,p,std", [(300, 200, False), (1000, 513, True)])
-def test_rotate_genotype_with_mean_imputed_missing(n, p, std, ctx):
+def test_rotate_genotype_with_mean_imputed_missing(n, p, std, kern, ctx, monkeypatch):
     """Columns whose missing calls were imputed with the column mean (one extra value per column, what the reference's
     callers feed: experiments/benchmarks/benchmarks.py:243-244) stay on the genotype path: codes + indicator pass."""
     from pygemma_amd import ops
+    _kernel_env(monkeypatch, kern)
     rng = np.random.default_rng(n)
     U = np.linalg.qr(rng.standard_normal((n, n)))[0].astype(np.float32)
     G = rng.binomial(2, rng.uniform(0.05, 0.5, p), size=(n, p)).astype(np.float64)
@@ -116,10 +169,12 @@ def test_rotate_genotype_with_mean_imputed_missing(n, p, std, ctx):
     assert (got[:, n:] == 0).all()
 
 
-def test_rotate_auto_device_side_path_choice_equals_host_side(ctx):
+@pytest.mark.parametrize("kern", ["i8", "f16"])
+def test_rotate_auto_device_side_path_choice_equals_host_side(kern, ctx, monkeypatch):
     """pg_rotate_auto_dev enqueues every candidate kernel predicated on the detect pass's flags (no host read-back): for each of
     the four kinds of block it must produce exactly what pg_rotate_geno_dev + the caller's fallback produce, and report the path."""
     from pygemma_amd import ops
+    _kernel_env(monkeypatch, kern)
     rng = np.random.default_rng(17)
     n, p = 321, 200
     U = np.linalg.qr(rng.standard_normal((n, n)))[0].astype(np.float32)
