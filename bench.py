@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TF = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU
 F16_MFMA_PEAK_TF = 2500.0  # dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md)
+I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA peak: 2x the bf16 rate per clock (MI355X_MICROARCH.md, MFMA table)
 F64_VALU_PEAK_TF = 78.6    # fp64 vector peak (= fp64 matrix peak on MI355X): 128 FLOP/clk/CU
 
 
@@ -269,7 +270,7 @@ def main():
             if int8:         # the same genotypes as the int8 matrix a caller may hand over (lmm.pygemma takes it as it is): 4x fewer bytes to scan
                 _lib.check(L.pg_rotate_auto_i8_dev(ctx.handle, n, pbn, dprep.ptr, dX8.ptr + s, 0, P, dXr.ptr, ldx, dwork.ptr, None),
                            "pg_rotate_auto_i8_dev")
-            elif not fp32:   # path chosen on the device from the block's values (genotype codes -> fp16x2 MFMA); no host read-back
+            elif not fp32:   # path chosen on the device from the block's values (genotype codes -> int8 digit-plane MFMA); no host read-back
                 _lib.check(L.pg_rotate_auto_dev(ctx.handle, n, pbn, dU.ptr, n, dprep.ptr, xptr + 4 * s, ldsrc, dXr.ptr, ldx, dwork.ptr,
                                                 dpath.ptr), "pg_rotate_auto_dev")
             else:
@@ -371,10 +372,17 @@ def main():
     # SURVEY 8(d) row S-brent as written: (4 E_b + 6 E_n) n m with m = c + 2 entries per evaluation (E_b counts the 11 scan points too)
     assoc_flops_snp_8d = (4.0 * (11 + stats[0]) + 6.0 * stats[1]) * n * m
     used_geno = (not a.fp32_rotate) and used_path == 1
-    tr_rot, src_rot, shape_rot = pmc_traffic("rotate_geno_kernel" if used_geno else "rotate_kernel")
+    geno_i8 = os.environ.get("PG_GENO_I8", "1") != "0"      # the library's default: genotype codes on the int8 pipe
+    tr_rot, src_rot, shape_rot = pmc_traffic(("rotate_geno_i8_kernel" if geno_i8 else "rotate_geno_kernel") if used_geno else "rotate_kernel")
     tr_as, src_as, shape_as = pmc_traffic("assoc_kernel")
     same_shape = (n, B, c) == shape_rot == shape_as          # the counters were collected per launch of this batch shape
-    rl_rotate = ({"kernel": "rotate_geno_kernel (+detect/encode): fp16 MFMA 16x16x32, U split in 2 fp16 planes, fp32 accumulate",
+    rl_rotate = ({"kernel": "rotate_geno_i8_kernel (+detect/encode): int8 MFMA 16x16x64, U as 3 int8 digit planes per eigenvector, exact int32 accumulate",
+                  "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12, "peak": I8_MFMA_PEAK_TOPS / 3.0, "unit": "TFLOP/s",
+                  "frac": rot_flops / rot_avg / 1e12 / (I8_MFMA_PEAK_TOPS / 3.0),
+                  "peak_note": "algorithmic 2n^2 flop/SNP against the dense int8 MFMA peak (5000 TOP/s) divided by the 3 int8 passes a "
+                               "24-bit U needs; executed int8 rate = 3x achieved (+ 1.1 % K padding and 1/256 pad rows)"}
+                 if used_geno and geno_i8 else
+                 {"kernel": "rotate_geno_kernel (+detect/encode): fp16 MFMA 16x16x32, U split in 2 fp16 planes, fp32 accumulate",
                   "bound": "mfma", "achieved": rot_flops / rot_avg / 1e12, "peak": F16_MFMA_PEAK_TF / 2.0, "unit": "TFLOP/s",
                   "frac": rot_flops / rot_avg / 1e12 / (F16_MFMA_PEAK_TF / 2.0),
                   "peak_note": "algorithmic 2n^2 flop/SNP against the dense fp16 MFMA peak (2500 TF) divided by the 2 fp16 passes a "
@@ -397,7 +405,9 @@ def main():
                 "traffic": tr_as if same_shape else None, "traffic_source": src_as if same_shape else None,
                 "algorithmic_bytes": (4.0 * ldx + 36) * B, "avg_launch_ms": assoc_avg * 1e3, "units_per_launch": B,
                 "flops_per_snp": assoc_flops_snp, "hbm_GBps_algorithmic": (4.0 * n + 36) * B / assoc_avg / 1e9}
-    rot_label = "f32 MFMA" if not used_geno else "f16x2->f32 MFMA (genotype codes exact; U in two fp16 planes)"
+    rot_label = ("f32 MFMA" if not used_geno else
+                 "i8x3->i32 MFMA (genotype codes exact, integer accumulation exact; U as 24-bit fixed point per eigenvector in three int8 planes)" if geno_i8
+                 else "f16x2->f32 MFMA (genotype codes exact; U in two fp16 planes)")
     out = {
         "metric": "SNPs/sec (whole node) at n=10,000 c=5; K-eigendecomp wallclock",
         "value": value, "unit": "SNPs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -422,7 +432,7 @@ def main():
         "roofline_eigh": ({"bound": "mfma", "achieved": 10.0 * n ** 3 / 3.0 / min(eigh_s) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                            "frac": 10.0 * n ** 3 / 3.0 / min(eigh_s) / 78.6e12, "flop_model": "10 n^3 / 3 (dsyevd count) / eigh_seconds",
                            "by_phase": "profiles/r04_syevd_summary.json"} if eigh_s else None),
-        "rotation_path": "fp32 MFMA (reference-arithmetic sgemm class)" if not used_geno else "genotype f16x2",
+        "rotation_path": "fp32 MFMA (reference-arithmetic sgemm class)" if not used_geno else ("genotype i8x3" if geno_i8 else "genotype f16x2"),
         "stage_snps_per_s_per_gpu": {"rotate": B / rot_avg, "assoc": B / assoc_avg},
         "evals_per_snp": {"fast": float(stats[0]), "newton": float(stats[1])},
         "lambda_median": float(np.median(lam)),
@@ -432,7 +442,7 @@ def main():
     if t_other is not None:
         key = "value_genotype_rotate" if a.fp32_rotate else "value_fp32_rotate"
         out[key] = {"value": P / t_other, "unit": "SNPs/s", "ms_per_step": 1e3 * t_other,
-                    "note": ("same pass with the fp16x2 genotype rotation" if a.fp32_rotate else
+                    "note": ("same pass with the genotype rotation" if a.fp32_rotate else
                              "same pass with the fp32-MFMA rotation forced (--fp32-rotate 1): the reference-arithmetic figure, bit-comparable "
                              "to an fp32 fma chain; also the rate for X holding NaN/Inf") + "; one untimed-by-the-metric pass"}
 

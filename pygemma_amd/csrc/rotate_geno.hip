@@ -618,24 +618,46 @@ struct GenoI8Params {
     const double *colsum, *wscale;   // wscale[k] = 2^(E_k - 22)
     float *Xr;
     int tiles_m, tiles_n, KT;
+    int nchunks, nc_base, nc_rem;    // the n-tiles go in nchunks chunks (the first nc_rem of nc_base + 1 tiles, the rest of nc_base): see the tile order
     const int *cond;
     int cmode;
 };
 
+#ifdef PG_GENO_STAMPS      // tools/geno_i8_stamps.py: s_memtime at the phase boundaries of stages 8 .. 23 of workgroup 0, waves 0 (early) and 4 (late)
+__device__ long long g_geno_stamps[2][16][6];
+#define GENO_STAMP(slot)                                                                                   \
+    do {                                                                                                   \
+        if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && kt >= 8 && kt < 24)                         \
+            g_geno_stamps[wave >> 2][kt - 8][slot] = (long long)__builtin_amdgcn_s_memtime();              \
+    } while (0)
+#else
+#define GENO_STAMP(slot) do { } while (0)
+#endif
 __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
 {
     if (!run_cond(gp.cond, gp.cmode)) return;
     constexpr int TBUF = 256 * 128;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     unsigned char *const Bs = lds, *const As = lds + 3 * TBUF;
-    const int T = gp.tiles_m * gp.tiles_n;
-    const int b = blockIdx.x;
-    const int q = T / 8, r = T % 8, xcd = b % 8;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-    const int per_group = PG_GENO_GRP * gp.tiles_n;
+    // Tile order.  Outermost: chunks of n-tiles small enough for their plane rows to stay in the 256 MB memory-side cache while ALL m-tiles
+    // pass over them (every XCD is in the same chunk at the same time; the misses of an XCD's L2 on the planes are then served from that
+    // cache instead of HBM).  Inside a chunk, as in the fp16 kernel: each XCD (workgroup id mod 8) takes a contiguous range of the order
+    // [group of PG_GENO_GRP m-tiles][n-tile][m-tile in group], so the 32 workgroups resident on an XCD share 4 genotype and 8 plane tiles.
+    // A chunk's tile count is padded to a multiple of 8 workgroups; the pad workgroups leave at once.
+    int b = blockIdx.x, tn0 = 0, nc = gp.nc_base + (gp.nc_rem > 0 ? 1 : 0);
+    for (int c = 0; c < gp.nchunks; c++) {
+        nc = gp.nc_base + (c < gp.nc_rem ? 1 : 0);
+        const int slots = (gp.tiles_m * nc + 7) / 8 * 8;
+        if (b < slots) break;
+        b -= slots; tn0 += nc;
+    }
+    const int Tc = gp.tiles_m * nc, qc = (Tc + 7) / 8;
+    const int lid = (b % 8) * qc + b / 8;
+    if (lid >= Tc) return;                             // pad slot (uniform over the workgroup, before any barrier)
+    const int per_group = PG_GENO_GRP * nc;
     const int grp = lid / per_group, first_m = grp * PG_GENO_GRP;
     const int gsz = (gp.tiles_m - first_m) < PG_GENO_GRP ? (gp.tiles_m - first_m) : PG_GENO_GRP;
-    const int tm = first_m + (lid % per_group) % gsz, tn = (lid % per_group) / gsz;
+    const int tm = first_m + (lid % per_group) % gsz, tn = tn0 + (lid % per_group) / gsz;
     const long long m0 = (long long)tm * 256, r0 = (long long)tn * 256, k0 = (long long)tn * I8_EIG;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves, each 64 (SNPs) x 128 (plane rows)
@@ -691,6 +713,7 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
         const int b2 = (b0 >= 1) ? b0 - 1 : 2;            // (kt + 2) % 3
         bool issued = false;
         // ---------------- memory phase
+        GENO_STAMP(0);
         if (late) { if (kt + 2 < gp.KT) { dmaB(kt + 2, b2); issued = true; } }
         else if (kt + 1 < gp.KT) dmaA(kt + 1);
         intx4 fa[2][4], fb[8];
@@ -710,10 +733,13 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
             if (issued) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        GENO_STAMP(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        GENO_STAMP(2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        GENO_STAMP(3);
         // ---------------- MFMA phase
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -728,7 +754,9 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[1][i], fb[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        GENO_STAMP(4);
         if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the genotype tile of the next stage is in LDS
+        GENO_STAMP(5);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -899,7 +927,15 @@ static int launch_geno_i8(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, 
     gp.wscale = (const double *)((const char *)Uprep + L.wscale);
     gp.v0 = v0; gp.dx = dx; gp.Xr = Xr;
     gp.tiles_m = (int)((p + 255) / 256); gp.tiles_n = (int)L.tiles8; gp.KT = (int)L.kt8;
-    const long long T = (long long)gp.tiles_m * gp.tiles_n;
+    // chunks of n-tiles whose plane rows fit PG_GENO_CHUNK_MB (default 100 MB of the 256 MB memory-side cache; 0: one chunk)
+    const char *ce = getenv("PG_GENO_CHUNK_MB");
+    const long long chunk_mb = ce ? atoll(ce) : 100;
+    long long ncmax = chunk_mb > 0 ? (chunk_mb << 20) / (256 * L.ldk8) : L.tiles8;
+    ncmax = ncmax < 8 ? 8 : ncmax;
+    gp.nchunks = (int)((L.tiles8 + ncmax - 1) / ncmax);
+    gp.nc_base = (int)(L.tiles8 / gp.nchunks); gp.nc_rem = (int)(L.tiles8 % gp.nchunks);
+    long long T = 0;
+    for (int c = 0; c < gp.nchunks; c++) T += ((long long)gp.tiles_m * (gp.nc_base + (c < gp.nc_rem ? 1 : 0)) + 7) / 8 * 8;
     PG_REQUIRE(T < (1LL << 31), "genotype rotation: too many tiles");
     constexpr int WLDS = 5 * 256 * 128;
     PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rotate_geno_i8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
@@ -1146,3 +1182,10 @@ extern "C" int pg_rotate_bed_dev(pg_ctx *ctx, int64_t n, int64_t p, const void *
     PG_HIP(hipStreamSynchronize(ctx->stream));
     return launch_geno_gemm(ctx, n, p, Uprep, Gt, Gi, v0, dx, dlt, Xr, ldx, hflag[1] != 0, nullptr, i8);
 }
+
+#ifdef PG_GENO_STAMPS
+extern "C" int pgx_geno_stamps(long long *out192)
+{
+    return hipMemcpyFromSymbol(out192, HIP_SYMBOL(pg::g_geno_stamps), sizeof(long long) * 192) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -52,7 +52,9 @@ summ["batch_shape"] = {"n": n, "batch": B, "c": int(_cfg["c"])}
 summ["kernel_stats_top"] = [{"kernel": r["Name"], "calls": int(r["Calls"]), "total_ms": float(r["TotalDurationNs"]) / 1e6,
                              "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])} for r in rows[:14]]
 pm = {}
-for key, kern, algo in (("rotate_geno_kernel", "rotate_geno_kernel", 2.0 * npad * B + 4.0 * n * npad + 4.0 * npad * B),
+npad8 = (n + 127) // 128 * 128
+for key, kern, algo in (("rotate_geno_i8_kernel", "rotate_geno_i8_kernel", 1.0 * npad8 * B + 3.0 * n * npad8 + 4.0 * npad * B),     # int8 codes, 3 int8 planes of U, fp32 out
+                        ("rotate_geno_kernel", "rotate_geno_kernel", 2.0 * npad * B + 4.0 * n * npad + 4.0 * npad * B),
                         ("assoc_kernel", "assoc_kernel<5", (4.0 * npad + 36) * B)):
     e = {}
     try:
@@ -76,6 +78,8 @@ for key, kern, algo in (("rotate_geno_kernel", "rotate_geno_kernel", 2.0 * npad 
             e["wait_frac_of_wave_cycles"] = wa / wv
     except Exception as ex:
         e["error"] = repr(ex)
+    if key.startswith("rotate_geno") and ("error" in e or e.get("avg_ms_profiled", 0.0) < 1.0):
+        continue            # that rotation kernel did not run in this profile, or only as predicated launches that leave at once (PG_GENO_I8 decides)
     pm[key] = e
 summ["pmc"] = pm
 try:
