@@ -633,6 +633,9 @@ __device__ long long g_geno_stamps[2][16][6];
 #else
 #define GENO_STAMP(slot) do { } while (0)
 #endif
+#ifndef PG_GENO_AUX
+#define PG_GENO_AUX 1      // cache-policy bits of the LDS-DMA loads (sc0 = 1, nt = 2): measured 0 / 1 / 2 / 3 -> rotation 24.9 / 24.6 / 37.3 / 37.7 ms per step (nt gives up the L2 reuse between the workgroups of an XCD)
+#endif
 __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
 {
     if (!run_cond(gp.cond, gp.cmode)) return;
@@ -686,14 +689,14 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
 #pragma unroll
         for (int t = 0; t < 8; t++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[t] + (size_t)stage * GBK8),
-                                             (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, PG_GENO_AUX);
     };
     auto dmaA = [&](int stage) {                     // early waves only: the wave's 64 rows of the genotype tile
         unsigned char *dst = As + (stage & 1) * TBUF + ((wave & 3) * 64) * 128;
 #pragma unroll
         for (int t = 0; t < 8; t++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[t] + (size_t)stage * GBK8),
-                                             (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, PG_GENO_AUX);
     };
     if (late) {
         dmaB(0, 0);

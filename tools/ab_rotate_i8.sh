@@ -1,6 +1,6 @@
 #!/bin/bash
 # int8 3-digit rotation (rotate_geno_i8_kernel, PG_GENO_I8=1) against the fp16 x 2 kernel (PG_GENO_I8=0) inside the bench step, under PMC passes:
-# matrix-pipe busy and issue stalls; LDS activity; L2 hits / misses; fabric fetches.  Only the launches that do the work (> 5 ms) are counted.
+# matrix-pipe busy and issue stalls; LDS activity; L2 hits / misses; fabric fetches.  Only the launches of the bench's 100 000-SNP step are counted (duration >= half of the kernel's longest).
 # Output: gpurun_out/ab_i8/summary.txt (copied to profiles/r04_rotate_i8_ab.txt)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$ROOT/gpurun_out/ab_i8; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -22,7 +22,9 @@ acc = collections.defaultdict(float); dur = []
 for i in (1, 2, 3, 4):
     fs = glob.glob("$OUT/v${v}_%d/**/c_counter_collection.csv" % i, recursive=True)
     if not fs: continue
-    rows = [r for r in csv.DictReader(open(fs[0])) if name in r["Kernel_Name"] and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 5e6]
+    rows = [r for r in csv.DictReader(open(fs[0])) if name in r["Kernel_Name"]]
+    dmax = max(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
+    rows = [r for r in rows if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) >= 0.5 * dmax]      # the 100 000-SNP launches only
     nl = len({r["Dispatch_Id"] for r in rows})
     for r in rows:
         key = r["Counter_Name"] if r["Counter_Name"] not in ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES") else r["Counter_Name"] + "_%d" % i
