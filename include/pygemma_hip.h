@@ -171,11 +171,13 @@ int pg_rotate_dev(pg_ctx *ctx, int64_t n, int64_t p, const float *U, int64_t ldU
                   float *Xr, int64_t ldx);
 
 /* ---- N4: rotation fast path for GENOTYPE columns (each column of the block takes <= 3 equally spaced
- * values: hard calls 0/1/2, raw or centred/standardised).  U'x = v0 (U'1) + dx (U'code): the codes are exact in fp16,
- * U (scaled by a power of two) is split once into two fp16 planes by round-to-nearest (11 + 11 significant bits plus
- * the sign of the second plane: residual <= 2^-23 |U| in the worst case, 2^-24 |U| typically — within one bit of float32's
- * own rounding of U), the products are exact in fp32 and accumulate in fp32 on the fp16 MFMA pipe
- * (same error class as pg_rotate_dev / the reference's sgemm, 8x fewer matrix cycles).  A column may also hold ONE other
+ * values: hard calls 0/1/2, raw or centred/standardised).  U'x = v0 (U'1) + dx (U'code): the codes are exact in int8,
+ * U is held once as a 24-bit fixed point per eigenvector in three int8 digit planes (|error| <= 2^-24 * 2 max_i |U[i][k]|:
+ * float32's own rounding for entries within a factor two of the column's largest), products and sums are EXACT on the int8
+ * MFMA pipe, and the three partial sums meet in fp64 with one rounding to float32 (error below pg_rotate_dev's / the
+ * reference's sgemm's fp32 accumulation on delocalised eigenvectors, within 3x of it on the adversarial ones of
+ * tests/test_gpu_rotate.py; 1/7 of its time).  PG_GENO_I8=0 selects the r2-r3 kernel instead: U split into two fp16 planes by
+ * round-to-nearest (residual <= 2^-23 |U|), fp32 accumulation on the fp16 MFMA pipe.  A column may also hold ONE other
  * value anywhere (missing calls imputed with the column mean, experiments/benchmarks/benchmarks.py:243-244): such blocks
  * take a second, accumulating pass on the 0/1 indicator plane.
  * Finite blocks that are not genotype-valued (imputed dosages, any float X) take the same GEMM with X itself split into two
