@@ -607,6 +607,11 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 // Every stage now brings a new genotype tile (no second plane to reuse it for): the early waves stage the whole 32 KB tile of stage
 // s+1 during stage s (8 DMA instructions per wave, waited at the END of their MFMA phase), into the buffer whose last readers — the
 // late waves' memory phase of stage s-1 — finished one barrier earlier.
+// Measured and rejected (r4): ONE barrier per stage (late waves stage the plane tile right after the barrier, nothing forces the phases
+// to alternate, both waves of a SIMD may issue MFMAs together): 27.0 ms against 23.7 per step — the DMA issue blocks on the full
+// vector-memory queue for ~900 cycles, and in that form it sits in front of the wave's own MFMAs instead of under its partner's.
+// An L2 prefetch (each sharer of a tile touching its 1/8 or 1/4 of the K-slice 2 or 4 stages ahead, one byte per line): 24.4 / 24.7 ms
+// against 24.2 — the DMAs do not wait on one another's fills.  Wave priorities (none / MFMA phase / + DMA issue): 24.3 / 24.2 / 24.1.
 typedef int intx4 __attribute__((ext_vector_type(4)));
 constexpr int GBK8 = 128;      // samples per K-tile (int8): 128-byte rows again
 constexpr int I8_EIG = 85;     // eigen indices per 256-row tile of the plane matrix (3 x 85 = 255)
@@ -636,6 +641,9 @@ __device__ long long g_geno_stamps[2][16][6];
 #ifndef PG_GENO_AUX
 #define PG_GENO_AUX 1      // cache-policy bits of the LDS-DMA loads (sc0 = 1, nt = 2): measured 0 / 1 / 2 / 3 -> rotation 24.9 / 24.6 / 37.3 / 37.7 ms per step (nt gives up the L2 reuse between the workgroups of an XCD)
 #endif
+#ifndef PG_GENO_PRIO
+#define PG_GENO_PRIO 1      // 0: no wave priorities, 1: the MFMA phase at priority 1, 2: and the DMA issue of the memory phase at 3
+#endif
 __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
 {
     if (!run_cond(gp.cond, gp.cmode)) return;
@@ -662,7 +670,7 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
     const int gsz = (gp.tiles_m - first_m) < PG_GENO_GRP ? (gp.tiles_m - first_m) : PG_GENO_GRP;
     const int tm = first_m + (lid % per_group) % gsz, tn = tn0 + (lid % per_group) / gsz;
     const long long m0 = (long long)tm * 256, r0 = (long long)tn * 256, k0 = (long long)tn * I8_EIG;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;     // wave: uniform, and the compiler is told so
     const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves, each 64 (SNPs) x 128 (plane rows)
 
     intx4 acc[4][8];
@@ -675,27 +683,33 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
 
     const bool late = wave >= 4;
     const int lrow = lane >> 3, lchunk = lane & 7;
-    const unsigned char *gsrc[8];
+    // DMA sources as a uniform 64-bit base (scalar registers; advanced by the stage) + a 32-bit per-lane offset that never changes:
+    // the saddr form of global_load_lds, no vector address arithmetic in the loop (24 VALU instructions per wave and stage before —
+    // each of them takes an issue slot from the partner wave's MFMAs)
+    const unsigned char *const gbase = late ? reinterpret_cast<const unsigned char *>(gp.Up8 + r0 * gp.ldk8)      // the plane matrix is padded to whole tiles
+                                            : reinterpret_cast<const unsigned char *>(gp.Gt8 + m0 * gp.ldk8);
+    unsigned voff[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         const int row = (wave & 3) * 64 + 8 * t + lrow;
-        long long rm = m0 + row;
-        rm = rm < gp.p ? rm : gp.p - 1;
-        gsrc[t] = (late ? reinterpret_cast<const unsigned char *>(gp.Up8 + (r0 + row) * gp.ldk8)      // the plane matrix is padded to whole tiles
-                        : reinterpret_cast<const unsigned char *>(gp.Gt8 + rm * gp.ldk8)) + swz(row, lchunk) * 16;
+        const long long rmax = gp.p - 1 - m0;        // rows past the end of the genotype block are clamped (their outputs are never stored)
+        const long long rr = late ? row : (row < rmax ? row : rmax);
+        voff[t] = (unsigned)(rr * gp.ldk8) + swz(row, lchunk) * 16;
     }
     auto dmaB = [&](int stage, int buf) {            // late waves only
         unsigned char *dst = Bs + buf * TBUF + ((wave & 3) * 64) * 128;
+        const unsigned char *src = gbase + (size_t)stage * GBK8;
 #pragma unroll
         for (int t = 0; t < 8; t++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[t] + (size_t)stage * GBK8),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff[t]),
                                              (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, PG_GENO_AUX);
     };
     auto dmaA = [&](int stage) {                     // early waves only: the wave's 64 rows of the genotype tile
         unsigned char *dst = As + (stage & 1) * TBUF + ((wave & 3) * 64) * 128;
+        const unsigned char *src = gbase + (size_t)stage * GBK8;
 #pragma unroll
         for (int t = 0; t < 8; t++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[t] + (size_t)stage * GBK8),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + voff[t]),
                                              (__attribute__((address_space(3))) void *)(dst + 8 * t * 128), 16, 0, PG_GENO_AUX);
     };
     if (late) {
@@ -707,9 +721,9 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    const int chunk0 = lane >> 4;
     if (late) __builtin_amdgcn_s_barrier();
     int b0 = 0;
-    const int chunk0 = lane >> 4;
     for (int kt = 0; kt < gp.KT; kt++) {
         const unsigned char *Acur = As + (kt & 1) * TBUF;
         const unsigned char *Bcur = Bs + b0 * TBUF;
@@ -717,8 +731,14 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
         bool issued = false;
         // ---------------- memory phase
         GENO_STAMP(0);
+#if PG_GENO_PRIO == 2
+        __builtin_amdgcn_s_setprio(3);
+#endif
         if (late) { if (kt + 2 < gp.KT) { dmaB(kt + 2, b2); issued = true; } }
         else if (kt + 1 < gp.KT) dmaA(kt + 1);
+#if PG_GENO_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         intx4 fa[2][4], fb[8];
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
@@ -744,7 +764,9 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
         __builtin_amdgcn_sched_barrier(0);
         GENO_STAMP(3);
         // ---------------- MFMA phase
+#if PG_GENO_PRIO >= 1
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int j = 0; j < 8; j++) {
 #pragma unroll
@@ -756,7 +778,9 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_i8_kernel(GenoI8Params gp)
         for (int j = 0; j < 8; j++)
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[1][i], fb[j], acc[i][j], 0, 0, 0);
+#if PG_GENO_PRIO >= 1
         __builtin_amdgcn_s_setprio(0);
+#endif
         GENO_STAMP(4);
         if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the genotype tile of the next stage is in LDS
         GENO_STAMP(5);
@@ -939,7 +963,7 @@ static int launch_geno_i8(pg_ctx *ctx, int64_t n, int64_t p, const void *Uprep, 
     gp.nc_base = (int)(L.tiles8 / gp.nchunks); gp.nc_rem = (int)(L.tiles8 % gp.nchunks);
     long long T = 0;
     for (int c = 0; c < gp.nchunks; c++) T += ((long long)gp.tiles_m * (gp.nc_base + (c < gp.nc_rem ? 1 : 0)) + 7) / 8 * 8;
-    PG_REQUIRE(T < (1LL << 31), "genotype rotation: too many tiles");
+    PG_REQUIRE(T < (1LL << 31) && L.ldk8 < (1LL << 24), "genotype rotation: too many tiles");      // 32-bit lane offsets: 256 rows x ldk8 bytes
     constexpr int WLDS = 5 * 256 * 128;
     PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rotate_geno_i8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS));
     gp.cond = cond; gp.cmode = cond ? cmode : COND_ALWAYS;
