@@ -612,6 +612,11 @@ __global__ __launch_bounds__(512, 1) void rotate_geno_kernel(GenoParams gp)
 // vector-memory queue for ~900 cycles, and in that form it sits in front of the wave's own MFMAs instead of under its partner's.
 // An L2 prefetch (each sharer of a tile touching its 1/8 or 1/4 of the K-slice 2 or 4 stages ahead, one byte per line): 24.4 / 24.7 ms
 // against 24.2 — the DMAs do not wait on one another's fills.  Wave priorities (none / MFMA phase / + DMA issue): 24.3 / 24.2 / 24.1.
+// The genotype tile nibble-packed (two codes per byte, unpacked by 48 VALU per wave and stage; 48 KB per stage, a third genotype buffer, no
+// wait for that tile any more): 24.05 against 23.95 — the time is set by the MFMA phases (one wave alone issues a 16 x 16 x 64 MFMA every
+// 20 cycles, not 16: 1 300 cycles per phase; with the unpacking beside it 1 490), not by the bytes.  v_mfma_i32_32x32x32_i8 in the same
+// loop (one wave fills the pipe with it in isolation): 30.8 ms — 45 cycles per MFMA and 1 500 cycles for the partner wave to issue its 8
+// DMAs: while a wave streams 32 x 32 MFMAs the other wave of the SIMD hardly issues at all (the fp16 kernel's 32 x 32 form lost the same way).
 typedef int intx4 __attribute__((ext_vector_type(4)));
 constexpr int GBK8 = 128;      // samples per K-tile (int8): 128-byte rows again
 constexpr int I8_EIG = 85;     // eigen indices per 256-row tile of the plane matrix (3 x 85 = 255)
