@@ -852,7 +852,8 @@ __global__ void i8_scale_kernel(long long n, const int *key, float *qscale, doub
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const float mx = __int_as_float(key[k]);
-    int E = ((key[k] >> 23) & 0xFF) - 127;                 // floor(log2 max); NaN / Inf never reach the int8 path (block flags)
+    int E = ((key[k] >> 23) & 0xFF) - 127;                 // floor(log2 max)
+    if (E == 128) { qscale[k] = 0.0f; wscale[k] = __longlong_as_double(0x7FF8000000000000LL); return; }   // a NaN / Inf in eigenvector k: its outputs are NaN, as in the fp16 and fp32 kernels
     if (!(mx > 0.0f) || E < -100) { qscale[k] = 1.0f; wscale[k] = 1.0; return; }     // an all-zero (or vanishing) column: q = 0
     if (ldexpf(mx, 22 - E) > 8355711.0f) E++;              // 127 * 65536 + 127 * 256 + 127: the top digit must stay <= 127
     qscale[k] = ldexpf(1.0f, 22 - E);

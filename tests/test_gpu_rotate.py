@@ -115,6 +115,26 @@ def test_rotate_int8_planes_with_localised_eigenvectors(kind, ctx, monkeypatch):
         assert (got[:, :n] == X.T).all()
 
 
+def test_rotate_int8_planes_nonfinite_eigenvector(ctx, monkeypatch):
+    """A NaN or an Inf inside eigenvector k makes output column k NaN (what 0 * NaN gives the float kernels) and leaves the other
+    columns alone: the digit planes are scaled per eigenvector."""
+    from pygemma_amd import ops
+    monkeypatch.setenv("PG_GENO_I8", "1")
+    rng = np.random.default_rng(5)
+    n, p = 300, 70
+    U = np.linalg.qr(rng.standard_normal((n, n)))[0].astype(np.float32)
+    U[17, 3] = np.nan; U[200, 9] = np.inf
+    X = _geno(rng, n, p, True)
+    got, ok = ops.rotate_geno(U, X, ctx=ctx)
+    assert ok == 1
+    bad = np.zeros(n, bool); bad[[3, 9]] = True
+    assert np.isnan(got[:, :n][:, bad]).all()
+    Uc = U.astype(np.float64)[:, ~bad]
+    exact = (Uc.T @ X.astype(np.float64)).T
+    bound = np.abs(X.astype(np.float64)).T @ np.abs(Uc)
+    assert (np.abs(got[:, :n][:, ~bad] - exact) <= 4 * 2.0 ** -24 * np.sqrt(n) * bound).all()
+
+
 def test_rotate_non_genotype_block_split_path_and_nan_rejection(ctx):
     """A finite block that is not genotype-valued (imputed dosages) goes through the same fp16 GEMM with X split in two
     fp16 planes (is_geno = 2), within the fp32-GEMM error class; a block with a NaN is left to the fp32 kernel."""
