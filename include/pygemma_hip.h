@@ -130,6 +130,11 @@ int pg_assoc_dev(pg_ctx *ctx, int64_t n, int c, int64_t p, const float *d, const
  * pg_assoc_dev calls on this context write, per SNP, fast evaluations | full (Newton) evaluations << 16 into trace_dev
  * (device, >= p entries, caller-owned); NULL switches the trace off. */
 int pg_assoc_set_eval_trace(pg_ctx *ctx, unsigned *trace_dev);
+/* Optional: what the FIRST pg_assoc_dev / pg_assoc_lrt_dev call of a context does on the host before it can enqueue its kernels (the
+ * float32-sum plan of numpy's add.reduce for length n: built on the host, uploaded after a stream drain; scratch allocations for c
+ * covariates) — ahead of time.  A streaming caller (lmm/lmm.py:461-495's per-SNP loop cut into batches) calls it while its first batch is
+ * still on the host link.  No reference counterpart: the reference has no device. */
+int pg_assoc_warm(pg_ctx *ctx, int64_t n, int c);
 
 /* ---- N2: the same operator plus the likelihood-ratio test the reference sketches and leaves commented out
  * ("Fix these calculations later", lmm/lmm.py:137-141, 277-300), built from its own ML functions: lambda_alt =

@@ -22,7 +22,7 @@ SYMBOLS = [
     "pg_memcpy_d2d_async", "pg_memcpy2d_h2d_async", "pg_stage_rows", "pg_event_sync", "pg_stream_wait_event",
     "pg_comm_unique_id", "pg_comm_init_rank", "pg_comm_init_all", "pg_comm_destroy", "pg_comm_size", "pg_comm_rank",
     "pg_comm_broadcast_dev", "pg_comm_allgather_dev", "pg_comm_allreduce_f64_dev", "pg_comm_barrier", "pg_comm_group_start",
-    "pg_comm_group_end", "pgx_dgemm_dev", "pgx_sytrd_dev", "pgx_stedc_dev", "pgx_sb2_stage1_dev", "pgx_sb2_stage2_dev", "pgx_sb2_set_debug", "pg_kinship_geno_dev", "pg_assoc_lrt_dev", "pg_rotate_auto_dev", "pg_assoc_set_eval_trace", "pg_rotate_auto_i8_dev",
+    "pg_comm_group_end", "pgx_dgemm_dev", "pgx_sytrd_dev", "pgx_stedc_dev", "pgx_sb2_stage1_dev", "pgx_sb2_stage2_dev", "pgx_sb2_set_debug", "pg_kinship_geno_dev", "pg_assoc_lrt_dev", "pg_rotate_auto_dev", "pg_assoc_set_eval_trace", "pg_assoc_warm", "pg_rotate_auto_i8_dev",
     "pg_zkzt_dev", "pgx_dgemm_ex_dev", "pgx_ring_stamps",
 ]
 
@@ -78,6 +78,8 @@ def load():
     L.pg_rotate_geno_dev.restype = i32
     L.pg_assoc_set_eval_trace.argtypes = [vp, vp]
     L.pg_assoc_set_eval_trace.restype = i32
+    L.pg_assoc_warm.argtypes = [vp, i64, i32]
+    L.pg_assoc_warm.restype = i32
     L.pg_rotate_auto_i8_dev.argtypes = [vp, i64, i64, vp, vp, i32, i64, vp, i64, vp, vp]
     L.pg_rotate_auto_i8_dev.restype = i32
     L.pg_rotate_auto_dev.argtypes = [vp, i64, i64, vp, i64, vp, vp, i64, vp, i64, vp, vp]
