@@ -188,12 +188,16 @@ def test_every_entry_point_rejects_bad_arguments_before_any_launch(ctx):
         ("pg_zkzt_dev ldz < q", lambda: L.pg_zkzt_dev(h, n, 8, b, 0, 7, b, 0, 8, b, n)),
         ("pg_zkzt_dev ldo < n", lambda: L.pg_zkzt_dev(h, n, 8, b, 0, 8, b, 0, 8, b, n - 1)),
         ("pg_zkzt_dev NULL K", lambda: L.pg_zkzt_dev(h, n, 8, b, 0, 8, None, 0, 8, b, n)),
+        ("pg_assoc_warm n = 1", lambda: L.pg_assoc_warm(h, 1, c)),
+        ("pg_assoc_warm c = 0", lambda: L.pg_assoc_warm(h, n, 0)),
+        ("pg_assoc_warm c too large", lambda: L.pg_assoc_warm(h, n, 1000)),
     ]
     for name, call in bad:
         rc = call()
         assert rc < 0, (name, rc)
         assert len(L.pg_last_error()) > 0, name
     assert L.pg_assoc_dev(h, n, c, 0, b, b, b, b, ok_ld, 0, b, b, b, b, b, b, None) == 0      # an empty block is not an error
+    assert L.pg_assoc_warm(h, n, c) == 0 and L.pg_assoc_warm(h, n, c) == 0                     # set-up ahead of time, twice: no harm
     buf.free()
     # the context still computes
     rp = synth.rotated_panel(n, p, c, seed=3)
