@@ -1234,6 +1234,9 @@ __device__ __forceinline__ u32x4 pack2(double a, double b)
 constexpr int BC_DONE = INT_MAX / 2;
 #ifndef PG_BC_EARLY_SEND
 #define PG_BC_EARLY_SEND 1
+#ifndef PG_BC_RAW_BARRIER
+#define PG_BC_RAW_BARRIER 1
+#endif
 #endif
 // debugging aid (pgx_sb2_set_debug): a host-mapped int array the bulge-chasing kernel leaves its position in (sweep, step, phase)
 static int *g_bc_debug = nullptr;
@@ -1482,6 +1485,15 @@ __device__ __forceinline__ void bc_give_up(int *ctl, int *fail, int s, int K)
     if ((++(spins_) & 63) == 0 &&                                                                                                 \
         ((spins_) > (1 << 20) || __hip_atomic_load(&(ctl_)[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { (bad_) = true; break; }
 
+#ifdef PG_BCS_TIME      // tools/bcs_time.py: s_memtime at the phase boundaries of workgroup 40, sweeps 2000 .. 5999, summed per phase
+__device__ long long g_bcs_time[12];
+#ifndef PG_BCS_WAVE
+#define PG_BCS_WAVE 0
+#endif
+#define BCS_T(ix) do { if (K == 40 && tid == 64 * PG_BCS_WAVE && s >= 2000 && s < 6000) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); if (!(s == 2000 && (ix) == 0)) g_bcs_time[ix] += t_ - bcs_last; bcs_last = t_; } } while (0)
+#else
+#define BCS_T(ix) do { } while (0)
+#endif
 template <int NWT>      // wavefronts per workgroup: 16 (one workgroup per CU) or 8 (two per CU: matrices of up to 2 x 64 x CUs rows)
 __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *S, double *VV, double *TAU, int nk, double *mail, int nwg, int *ctl, int *fail, int test_fault)
 {
@@ -1511,9 +1523,13 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
     if (tid == 0) { sc[2] = 0.0; *abort_sh = 0; }
     __syncthreads();
     int s = 0;
+#ifdef PG_BCS_TIME
+    long long bcs_last = (long long)__builtin_amdgcn_s_memtime();
+#endif
     for (; s <= n - 3; s++) {
         const int r0 = s + 1 + K * B;
         if (r0 >= n) break;
+        BCS_T(0);      // loop overhead + final barrier of the previous step
         const int L = (n - r0 < B) ? n - r0 : B;
         const int eb = (r0 - B) & (SB_LD - 1), db = r0 & (SB_LD - 1), rb = r0 & (B - 1);
         const int ecol = (eb + lane) & (SB_LD - 1), dcol = (db + lane) & (SB_LD - 1);
@@ -1560,30 +1576,61 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
             if (lane == 0) sc[2] = mb_value(c1);
         }
         __syncthreads();
+        BCS_T(1);      // waiting for the two messages (+ barrier)
         if (*abort_sh != 0) return;
         const double taup = sc[2];
         double x0 = 0.0;
-        // ---- (1) right-apply the reflector from above to E (lane = row, wq = RW columns)
+        // ---- (1) right-apply the reflector from above to E (lane = row, wq = RW columns).  (r4: lane = column, wq = RW whole rows with the
+        // rows' dot products as DPP reductions — no partial sums through LDS, no barrier inside the phase — is SLOWER: stage 2 58.4 against
+        // 55.5 ms; four 64-lane f64 reductions per wavefront cost more than the NW partial sums they replace.)
         if (K >= 1) {
             double s_ = 0.0;
 #pragma unroll
             for (int c = RW * wq; c < RW * wq + RW; c++) s_ = fma(Wn[EIX(lane, c)], vprev[c], s_);
             part[wq][lane] = s_;
             __syncthreads();
-            double u = 0.0;
-#pragma unroll
-            for (int w_ = 0; w_ < NW; w_++) u += part[w_][lane];
-            const double tu = taup * u;
+            // the NW partials of a row are summed ONCE: wavefront wq takes the rows RW wq .. (lane -> row lane / NW, partial lane % NW; a DPP
+            // reduction over groups of NW lanes), tau' u goes through LDS (wv is free here) — one more barrier, but every thread summing all
+            // NW partials of its row read 16 x 8 KB from LDS per step, the longest item between the messages' arrival and the reflector's
+            // departure (r4: 2 430 cycles for this phase, on the sweeps' critical cycle twice)
+            {
+                double t = part[lane % NW][RW * wq + lane / NW];
+                t += dpp_mov(t, 0);
+                t += dpp_mov(t, 1);
+                if (NW >= 8) t += dpp_mov(t, 2);
+                if (NW >= 16) t += dpp_mov(t, 3);
+                if (lane % NW == 0) wv[RW * wq + lane / NW] = taup * t;
+            }
+            __syncthreads();
+            const double tu = wv[lane];
 #pragma unroll
             for (int c = RW * wq; c < RW * wq + RW; c++) Wn[EIX(lane, c)] = fma(-tu, vprev[c], Wn[EIX(lane, c)]);
             if (wq == 0) x0 = Wn[EIX(lane, 0)];
         } else if (wq == 0) x0 = Wn[EIX(lane, B - 1)];
+        BCS_T(2);      // right-apply (dot, barrier, update)
         // ---- (2) reflector (wave 0)
         if (wq == 0) {
             const double alpha = readlane_d(x0, 0);
             const double xn2 = wave_sum_dpp((lane >= 1) ? x0 * x0 : 0.0);
             double beta = alpha, tau = 0.0, scal = 0.0;
-            if (xn2 != 0.0) { beta = -copysign(sqrt(alpha * alpha + xn2), alpha); tau = (beta - alpha) / beta; scal = 1.0 / (alpha - beta); }
+            if (xn2 != 0.0) {
+                const double nn = alpha * alpha + xn2;
+                if (nn > 1.0e-280 && nn < 1.0e280) {
+                    // the square root and the two divisions of the textbook formulas are ~800 cycles of dependent IEEE expansions, and this
+                    // wavefront's path from the messages' arrival to the reflector's departure is on the sweeps' critical cycle twice:
+                    // v_rsq / v_rcp + Newton steps instead (to the last bit or two; what matters is tau v'v = 2 to rounding, as before)
+                    const double r = rsqrt_newton(nn);
+                    double nrm = nn * r;
+                    nrm = fma(0.5 * r, fma(-nrm, nrm, nn), nrm);                  // sqrt(nn)
+                    beta = -copysign(nrm, alpha);
+                    tau = fma(fabs(alpha), r, 1.0);                               // (beta - alpha) / beta = 1 + |alpha| / nrm
+                    const double den = fabs(alpha) + nrm;                         // alpha - beta = sign(alpha) (|alpha| + nrm)
+                    double ri = __builtin_amdgcn_rcp(den);
+                    ri = fma(ri, fma(-den, ri, 1.0), ri);
+                    ri = fma(ri, fma(-den, ri, 1.0), ri);
+                    scal = copysign(ri, alpha);
+                } else { beta = -copysign(sqrt(nn), alpha); tau = (beta - alpha) / beta; scal = 1.0 / (alpha - beta); }
+            }
             const double v = (lane == 0) ? 1.0 : x0 * scal;
             // the reflector leaves for workgroup K + 1 straight from this wavefront's registers, BEFORE the barrier (r4; r3: from the last
             // wavefront behind it): the time from the messages' arrival to this store is on the sweeps' critical cycle twice
@@ -1598,6 +1645,7 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
             Wn[EIX(lane, (K >= 1) ? 0 : B - 1)] = (lane == 0) ? beta : 0.0;
         }
         __syncthreads();
+        BCS_T(3);      // reflector + send + barrier
         const double tau = sc[0];
         if (!PG_BC_EARLY_SEND && wq == NW - 1 && r0 + B < n) {
             const unsigned tag = (unsigned)(s + 1);
@@ -1617,6 +1665,7 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
             part2[wq][lane] = sp;
         }
         __syncthreads();
+        BCS_T(4);      // w = E'v, p = D v partial sums + barrier
         if (wq == 0) {
             double w_ = 0.0;
 #pragma unroll
@@ -1632,6 +1681,7 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
             qv[lane] = p - 0.5 * tau * pv * vcur[lane];
         }
         __syncthreads();
+        BCS_T(5);      // the two reductions + barrier
         // ---- (3b), (4b) rank updates in place (lane = column, wq = RW rows)
         {
             const double wc = wv[lane], qc = qv[lane], vc = vcur[lane];
@@ -1640,19 +1690,29 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
                 const double vr = vcur[r], qr = qv[r];
                 if (K >= 1 && lane >= 1) Wn[ROW(r) + ecol] = fma(-tau * vr, wc, Wn[ROW(r) + ecol]);
                 if (lane <= r) Wn[ROW(r) + dcol] -= vr * qc + qr * vc;
+                // the top row is finished as soon as wavefront 0 has updated it (its first row): it leaves for workgroup K - 1 (or for
+                // memory) BEFORE the wavefront's other rows — the row's arrival starts the neighbour's next step (r4: it left after them)
+                if (r == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wavefront's own LDS writes of row 0
+                    const double a_ = Wn[ROW(0) + 2 * lane], b_ = Wn[ROW(0) + 2 * lane + 1];
+                    if (K == 0) __builtin_amdgcn_raw_buffer_store_b128(pack2(a_, b_), rsrc, (unsigned)((r0 * SB_LD + 2 * lane) * 8), 0, 0);
+                    else {
+                        const unsigned tag = (unsigned)(s + 1), off = (unsigned)(K * MB_LD * 8 + 32 * lane);
+                        __builtin_amdgcn_raw_buffer_store_b128(mb_pack(a_, tag), rmail, off, 0, BC_SC1);
+                        __builtin_amdgcn_raw_buffer_store_b128(mb_pack(b_, tag), rmail, off + 16, 0, BC_SC1);
+                    }
+                }
             }
         }
-        // the top row is finished (all of it was updated by this wavefront): it leaves for workgroup K - 1, or for memory
-        if (wq == 0) {
-            const double a_ = Wn[ROW(0) + 2 * lane], b_ = Wn[ROW(0) + 2 * lane + 1];
-            if (K == 0) __builtin_amdgcn_raw_buffer_store_b128(pack2(a_, b_), rsrc, (unsigned)((r0 * SB_LD + 2 * lane) * 8), 0, 0);
-            else {
-                const unsigned tag = (unsigned)(s + 1), off = (unsigned)(K * MB_LD * 8 + 32 * lane);
-                __builtin_amdgcn_raw_buffer_store_b128(mb_pack(a_, tag), rmail, off, 0, BC_SC1);
-                __builtin_amdgcn_raw_buffer_store_b128(mb_pack(b_, tag), rmail, off + 16, 0, BC_SC1);
-            }
-        }
+        BCS_T(6);      // rank updates + top row out
+#if PG_BC_RAW_BARRIER
+        // end of the step: the LDS writes of the updates must be visible to the next step; the mailbox stores just issued need NOT have
+        // been acknowledged (a __syncthreads() here waits for them: s_waitcnt vmcnt(0) in front of the barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#else
         __syncthreads();
+#endif
 #undef ROW
 #undef EIX
 #undef DIX
@@ -1707,6 +1767,13 @@ int sb2st_device(pg_ctx *ctx, int n, const double *A, double *d, double *e, Sb2W
         if (stationary) {
             PG_HIP(hipMemsetAsync(w.mail, 0, (size_t)nblk * MB_LD * 8, st));
             const int test_fault = (getenv("PG_BC_TEST_FAULT") && atoi(getenv("PG_BC_TEST_FAULT")) != 0) ? 1 : 0;
+            const int exp_waves = getenv("PG_BC_STAT_WAVES") ? atoi(getenv("PG_BC_STAT_WAVES")) : 0;      // A/B: wavefronts per workgroup of the one-per-CU form
+            if (per_cu == 1 && exp_waves == 8) bc_stationary_kernel<8><<<nblk, 64 * 8, BC_LDS8, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.mail, nblk, w.prog + n, w.fail, test_fault);
+            else if (per_cu == 1 && exp_waves == 4) {
+                constexpr int BC_LDS4 = (B * WP + 4 * B + 2 * 4 * B + 4) * 8;
+                PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bc_stationary_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS4));
+                bc_stationary_kernel<4><<<nblk, 64 * 4, BC_LDS4, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.mail, nblk, w.prog + n, w.fail, test_fault);
+            } else
             if (per_cu == 1) bc_stationary_kernel<NW><<<nblk, 64 * NW, BC_LDS, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.mail, nblk, w.prog + n, w.fail, test_fault);
             else bc_stationary_kernel<8><<<nblk, 64 * 8, BC_LDS8, st>>>(n, w.S, w.VV, w.TAU, w.nk, w.mail, nblk, w.prog + n, w.fail, test_fault);
         } else {
@@ -2278,3 +2345,11 @@ int bt1_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w)
 }
 
 }  // namespace pg
+
+#ifdef PG_BCS_TIME
+extern "C" int pgx_bcs_time(long long *out12, int reset)
+{
+    if (reset) { long long z[12] = {0}; return hipMemcpyToSymbol(HIP_SYMBOL(pg::g_bcs_time), z, sizeof(z)) == hipSuccess ? 0 : -1; }
+    return hipMemcpyFromSymbol(out12, HIP_SYMBOL(pg::g_bcs_time), sizeof(long long) * 12) == hipSuccess ? 0 : -1;
+}
+#endif
