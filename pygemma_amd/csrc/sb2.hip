@@ -1234,6 +1234,9 @@ __device__ __forceinline__ u32x4 pack2(double a, double b)
 constexpr int BC_DONE = INT_MAX / 2;
 #ifndef PG_BC_EARLY_SEND
 #define PG_BC_EARLY_SEND 1
+#ifndef PG_BC_POLL_SLEEP
+#define PG_BC_POLL_SLEEP 1      // s_sleep units (64 clocks) between two polls of a mailbox
+#endif
 #ifndef PG_BC_RAW_BARRIER
 #define PG_BC_RAW_BARRIER 1
 #endif
@@ -1468,6 +1471,8 @@ __global__ __launch_bounds__(64 * NW) void bc_kernel(int n, double *S, double *V
 // 8-byte half validates itself (8-byte accesses are single-copy atomic) and the receiver polls the payload directly: no drain,
 // no separate flag, no second round trip (the first version — payload, s_waitcnt, sequence flag, then the receiver's two dependent
 // loads — spent 2.1 us per hop; the sweep period is two hops plus the work between them).
+// (r4, measured and rejected: four polls of a mailbox in flight, a quarter of a round trip apart, to sample the memory more often than once
+// per round trip — stage 2 59.4 against 51.9 ms: the extra reads of the line the neighbour is about to write delay that write.)
 //   mailbox of workgroup K (MB_LD doubles = 4 KB): chunks [0, 128) the row going up | chunks [128, 192) the reflector going down,
 //   chunk 192 its tau
 constexpr int MB_LD = SB_MAIL_LD, MB_V = 128, MB_TAU = 192;
@@ -1550,7 +1555,7 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
                     asm volatile("" ::: "memory");
                     if (__all(c0.y == want && c0.w == want && c1.y == want && c1.w == want)) break;
                     BC_POLL_GUARD(spins, ctl, bad)
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(PG_BC_POLL_SLEEP);
                 }
                 if (bad) { bc_give_up(ctl, fail, s, K); *abort_sh = 1; }
                 v0 = mb_value(c0); v1 = mb_value(c1);
@@ -1569,7 +1574,7 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
                 asm volatile("" ::: "memory");
                 if (__all(c0.y == want && c0.w == want && c1.y == want && c1.w == want)) break;
                 BC_POLL_GUARD(spins, ctl, bad)
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(PG_BC_POLL_SLEEP);
             }
             if (bad) { bc_give_up(ctl, fail, s, K); *abort_sh = 1; }
             vprev[lane] = mb_value(c0);
