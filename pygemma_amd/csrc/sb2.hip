@@ -1585,31 +1585,29 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
         if (*abort_sh != 0) return;
         const double taup = sc[2];
         double x0 = 0.0;
-        // ---- (1) right-apply the reflector from above to E (lane = row, wq = RW columns).  (r4: lane = column, wq = RW whole rows with the
-        // rows' dot products as DPP reductions — no partial sums through LDS, no barrier inside the phase — is SLOWER: stage 2 58.4 against
-        // 55.5 ms; four 64-lane f64 reductions per wavefront cost more than the NW partial sums they replace.)
+        // ---- (1) right-apply the reflector from above to E: E <- E - tau' (E v') v'^T.  NW lanes per row: thread -> row wq + NW (lane / NW), the RW
+        // columns lane % NW + NW cc; a row's dot product with v' is a DPP sum over its group of NW lanes, so nothing of this phase goes
+        // through LDS and there is no barrier inside it — one after it (wavefront 0 reads column 0 for the reflector).
+        // History of this phase, which is on the sweeps' critical cycle twice: lane = row, wq = RW columns, every thread adding the NW partials of
+        // its row from LDS behind a barrier 2 430 cycles; the partials added once per row (a second barrier) 2 130; whole rows per wavefront
+        // with 64-lane reductions (readlane) slower than either (stage 2 58.4 against 55.5 ms).
         if (K >= 1) {
-            double s_ = 0.0;
+            // rows wq, wq + NW, ..: with the pitch of 129 doubles the lane groups of a 32-lane LDS pass sit 32 banks apart; columns lane % NW + NW cc:
+            // the NW lanes of a group read consecutive doubles
+            const int rl = wq + NW * (lane / NW), c0 = lane % NW;
+            double er[RW], vp[RW], t = 0.0;
 #pragma unroll
-            for (int c = RW * wq; c < RW * wq + RW; c++) s_ = fma(Wn[EIX(lane, c)], vprev[c], s_);
-            part[wq][lane] = s_;
-            __syncthreads();
-            // the NW partials of a row are summed ONCE: wavefront wq takes the rows RW wq .. (lane -> row lane / NW, partial lane % NW; a DPP
-            // reduction over groups of NW lanes), tau' u goes through LDS (wv is free here) — one more barrier, but every thread summing all
-            // NW partials of its row read 16 x 8 KB from LDS per step, the longest item between the messages' arrival and the reflector's
-            // departure (r4: 2 430 cycles for this phase, on the sweeps' critical cycle twice)
-            {
-                double t = part[lane % NW][RW * wq + lane / NW];
-                t += dpp_mov(t, 0);
-                t += dpp_mov(t, 1);
-                if (NW >= 8) t += dpp_mov(t, 2);
-                if (NW >= 16) t += dpp_mov(t, 3);
-                if (lane % NW == 0) wv[RW * wq + lane / NW] = taup * t;
-            }
-            __syncthreads();
-            const double tu = wv[lane];
+            for (int cc = 0; cc < RW; cc++) { er[cc] = Wn[EIX(rl, c0 + NW * cc)]; vp[cc] = vprev[c0 + NW * cc]; }
 #pragma unroll
-            for (int c = RW * wq; c < RW * wq + RW; c++) Wn[EIX(lane, c)] = fma(-tu, vprev[c], Wn[EIX(lane, c)]);
+            for (int cc = 0; cc < RW; cc++) t = fma(er[cc], vp[cc], t);
+            t += dpp_mov(t, 0);
+            t += dpp_mov(t, 1);
+            if (NW >= 8) t += dpp_mov(t, 2);
+            if (NW >= 16) t += dpp_mov(t, 3);
+            const double tu = taup * t;
+#pragma unroll
+            for (int cc = 0; cc < RW; cc++) Wn[EIX(rl, c0 + NW * cc)] = fma(-tu, vp[cc], er[cc]);
+            __syncthreads();
             if (wq == 0) x0 = Wn[EIX(lane, 0)];
         } else if (wq == 0) x0 = Wn[EIX(lane, B - 1)];
         BCS_T(2);      // right-apply (dot, barrier, update)
