@@ -1234,12 +1234,12 @@ __device__ __forceinline__ u32x4 pack2(double a, double b)
 constexpr int BC_DONE = INT_MAX / 2;
 #ifndef PG_BC_EARLY_SEND
 #define PG_BC_EARLY_SEND 1
+#endif
 #ifndef PG_BC_POLL_SLEEP
 #define PG_BC_POLL_SLEEP 1      // s_sleep units (64 clocks) between two polls of a mailbox
 #endif
 #ifndef PG_BC_RAW_BARRIER
 #define PG_BC_RAW_BARRIER 1
-#endif
 #endif
 // debugging aid (pgx_sb2_set_debug): a host-mapped int array the bulge-chasing kernel leaves its position in (sweep, step, phase)
 static int *g_bc_debug = nullptr;
@@ -1499,6 +1499,14 @@ __device__ long long g_bcs_time[12];
 #else
 #define BCS_T(ix) do { } while (0)
 #endif
+// The barriers of a step order LDS accesses only: the mailbox stores (write-through, ~1 000 cycles to their acknowledgement) and the
+// reflector's copy to memory must NOT be waited for — __syncthreads() puts s_waitcnt vmcnt(0) in front of the barrier, and wavefront 0,
+// which sends, is the one every barrier of the step waits for.
+#if PG_BC_RAW_BARRIER
+#define BC_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define BC_BARRIER() __syncthreads()
+#endif
 template <int NWT>      // wavefronts per workgroup: 16 (one workgroup per CU) or 8 (two per CU: matrices of up to 2 x 64 x CUs rows)
 __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *S, double *VV, double *TAU, int nk, double *mail, int nwg, int *ctl, int *fail, int test_fault)
 {
@@ -1580,7 +1588,7 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
             vprev[lane] = mb_value(c0);
             if (lane == 0) sc[2] = mb_value(c1);
         }
-        __syncthreads();
+        BC_BARRIER();
         BCS_T(1);      // waiting for the two messages (+ barrier)
         if (*abort_sh != 0) return;
         const double taup = sc[2];
@@ -1607,7 +1615,7 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
             const double tu = taup * t;
 #pragma unroll
             for (int cc = 0; cc < RW; cc++) Wn[EIX(rl, c0 + NW * cc)] = fma(-tu, vp[cc], er[cc]);
-            __syncthreads();
+            BC_BARRIER();
             if (wq == 0) x0 = Wn[EIX(lane, 0)];
         } else if (wq == 0) x0 = Wn[EIX(lane, B - 1)];
         BCS_T(2);      // right-apply (dot, barrier, update)
@@ -1647,7 +1655,7 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
             if (lane < L) VV[(size_t)s * n + r0 + lane] = v;
             Wn[EIX(lane, (K >= 1) ? 0 : B - 1)] = (lane == 0) ? beta : 0.0;
         }
-        __syncthreads();
+        BC_BARRIER();
         BCS_T(3);      // reflector + send + barrier
         const double tau = sc[0];
         if (!PG_BC_EARLY_SEND && wq == NW - 1 && r0 + B < n) {
@@ -1667,7 +1675,7 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
             part[wq][lane] = sw;
             part2[wq][lane] = sp;
         }
-        __syncthreads();
+        BC_BARRIER();
         BCS_T(4);      // w = E'v, p = D v partial sums + barrier
         if (wq == 0) {
             double w_ = 0.0;
@@ -1683,7 +1691,7 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
             const double pv = wave_sum_dpp(p * vcur[lane]);
             qv[lane] = p - 0.5 * tau * pv * vcur[lane];
         }
-        __syncthreads();
+        BC_BARRIER();
         BCS_T(5);      // the two reductions + barrier
         // ---- (3b), (4b) rank updates in place (lane = column, wq = RW rows)
         {
@@ -1708,14 +1716,7 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
             }
         }
         BCS_T(6);      // rank updates + top row out
-#if PG_BC_RAW_BARRIER
-        // end of the step: the LDS writes of the updates must be visible to the next step; the mailbox stores just issued need NOT have
-        // been acknowledged (a __syncthreads() here waits for them: s_waitcnt vmcnt(0) in front of the barrier)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#else
-        __syncthreads();
-#endif
+        BC_BARRIER();
 #undef ROW
 #undef EIX
 #undef DIX
