@@ -171,6 +171,7 @@ extern "C" void pg_ctx_destroy(pg_ctx *ctx)
     if (ctx->stats) (void)hipFree(ctx->stats);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     if (ctx->plan.d_leaf) { (void)hipFree(ctx->plan.d_leaf); (void)hipFree(ctx->plan.d_node); (void)hipFree(ctx->plan.d_level); (void)hipFree(ctx->plan.d_chunk); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -58,6 +58,9 @@ struct pg_ctx {
     // the eigensolver's work arena, kept between solves up to 16 GiB (n <= ~14 000): a hipMalloc / hipFree pair
     // per solve was followed, in one solve out of three, by a kernel launch that blocked the host for 25 - 60 ms (r4, HIP API trace)
     void *arena = nullptr; size_t arena_bytes = 0;
+    // page-locked host staging of the divide & conquer's per-level tables (grown on demand, freed with the context): from pageable
+    // std::vectors every one of its ~8 small copies per level blocked the host for 50 - 100 us (5.5 ms of idle GPU per solve at n = 10 000)
+    void *hpin = nullptr; size_t hpin_bytes = 0;
 };
 
 namespace pg {

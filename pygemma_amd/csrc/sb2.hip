@@ -2276,6 +2276,7 @@ int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w, bool prepared)
             Bt2SArgs ar;
             ar.n = n; ar.ng = ng; ar.ts = ts; ar.u_first = u_lo; ar.Vp = w.Vp; ar.Vtp = w.Vtp; ar.Z = Z;
             ar.vec = ((n & 1) == 0 && (uintptr_t)Z % 16 == 0) ? 1 : 0;
+            if (const char *e_ = getenv("PG_BT2_VEC")) ar.vec = ar.vec && atoi(e_) != 0;      // A/B: 0 = the slab straight between memory and the MFMA layout
             bt2_apply4_kernel<<<dim3(nslab, u_hi - u_lo + 1), 256, BT2_LDS_BYTES, st>>>(ar);
         }
         PG_HIP(hipGetLastError());

@@ -876,40 +876,54 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
 
     double *Qin = wk.Qa, *Qout = wk.Qb;
     std::vector<int> blocks(bs);   // boundaries of the current level
-    std::vector<double> zhost(n), dnew(n);
-    std::vector<int> zrow(n), colbuf(n), rpbuf(n, 0);
+    // the tables that travel between host and device at every level live in page-locked memory kept with the context: the copies are
+    // then asynchronous in fact, not only in name (staged from pageable vectors each of them blocked the host)
+    const size_t nn = (size_t)n;
+    const size_t hp_need = nn * (8 + 8 + 4 + 4 + 4 + 16) + (nn + 1) * sizeof(Rot) + 1024;
+    if (ctx->hpin_bytes < hp_need) {
+        if (ctx->hpin) { (void)hipHostFree(ctx->hpin); ctx->hpin = nullptr; ctx->hpin_bytes = 0; }
+        PG_HIP(hipHostMalloc(&ctx->hpin, hp_need, hipHostMallocDefault));
+        ctx->hpin_bytes = hp_need;
+    }
+    double *zhost = (double *)ctx->hpin, *dnew = zhost + nn, *dlw = dnew + nn;      // dlw: 2 n
+    Rot *allrots = (Rot *)(dlw + 2 * nn);
+    int *zrow = (int *)(allrots + nn + 1), *colbuf = zrow + nn, *rpbuf = colbuf + nn;
+    std::fill(rpbuf, rpbuf + nn, 0);
     while (blocks.size() > 2) {
         const int nb = (int)blocks.size() - 1;
         std::vector<MergePlan> plans;
-        std::fill(zrow.begin(), zrow.end(), -1);
+        std::fill(zrow, zrow + nn, -1);
         for (int b = 0; b + 1 < nb; b += 2) {
             MergePlan mp; mp.s = blocks[b]; mp.n1 = blocks[b + 1] - blocks[b]; mp.nm = blocks[b + 2] - blocks[b];
             for (int i = 0; i < mp.nm; i++) zrow[mp.s + i] = (i < mp.n1) ? (mp.s + mp.n1 - 1) : (mp.s + mp.n1);
             plans.push_back(std::move(mp));
         }
-        PG_HIP(hipMemcpyAsync(wk.ibuf, zrow.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        PG_HIP(hipMemcpyAsync(wk.ibuf, zrow, (size_t)n * 4, hipMemcpyHostToDevice, st));
         gather_z_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, Qin, wk.ibuf, wk.z);
-        PG_HIP(hipMemcpyAsync(zhost.data(), wk.z, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        PG_HIP(hipMemcpyAsync(zhost, wk.z, (size_t)n * 8, hipMemcpyDeviceToHost, st));
         PG_HIP(hipStreamSynchronize(st));
         mark("  gather z", nb, 0);
         size_t rot_total = 0;
         for (auto &mp : plans) {
-            plan_merge(mp, d.data() + mp.s, zhost.data() + mp.s, e[mp.s + mp.n1 - 1]);
+            plan_merge(mp, d.data() + mp.s, zhost + mp.s, e[mp.s + mp.n1 - 1]);
             for (int i = 0; i < mp.nm; i++) colbuf[mp.s + i] = mp.col[i];
             for (int i = 0; i < mp.k; i++) rpbuf[mp.s + i] = mp.rowpos[i];
             rot_total += mp.rots.size();
         }
-        std::vector<Rot> allrots; allrots.reserve(rot_total + 1);
-        std::vector<double> dlw(2 * (size_t)n, 0.0);
-        for (auto &mp : plans) {
-            for (auto &r : mp.rots) allrots.push_back(r);
-            for (int i = 0; i < mp.k; i++) { dlw[mp.s + i] = mp.dl[i]; dlw[(size_t)n + mp.s + i] = mp.w[i]; }
+        PG_REQUIRE(rot_total <= nn, "stedc: more deflation rotations than rows");      // (a rotation deflates a row: at most nm - 1 per merge)
+        std::fill(dlw, dlw + 2 * nn, 0.0);
+        {
+            size_t at = 0;
+            for (auto &mp : plans) {
+                for (auto &r : mp.rots) allrots[at++] = r;
+                for (int i = 0; i < mp.k; i++) { dlw[mp.s + i] = mp.dl[i]; dlw[nn + mp.s + i] = mp.w[i]; }
+            }
         }
-        PG_HIP(hipMemcpyAsync(wk.ibuf + n, colbuf.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-        PG_HIP(hipMemcpyAsync(wk.ibuf + 2 * n, rpbuf.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));   // (the leaf tables are done with)
-        if (!allrots.empty()) PG_HIP(hipMemcpyAsync(wk.rots, allrots.data(), allrots.size() * sizeof(Rot), hipMemcpyHostToDevice, st));
-        PG_HIP(hipMemcpyAsync(wk.dl, dlw.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-        PG_HIP(hipMemcpyAsync(wk.w, dlw.data() + n, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        PG_HIP(hipMemcpyAsync(wk.ibuf + n, colbuf, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        PG_HIP(hipMemcpyAsync(wk.ibuf + 2 * n, rpbuf, (size_t)n * 4, hipMemcpyHostToDevice, st));   // (the leaf tables are done with)
+        if (rot_total > 0) PG_HIP(hipMemcpyAsync(wk.rots, allrots, rot_total * sizeof(Rot), hipMemcpyHostToDevice, st));
+        PG_HIP(hipMemcpyAsync(wk.dl, dlw, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        PG_HIP(hipMemcpyAsync(wk.w, dlw + nn, (size_t)n * 8, hipMemcpyHostToDevice, st));
         mark("  plan+copy", nb, 0);
         size_t roff = 0;
         int nm_max = 0, k_max = 0;
@@ -980,7 +994,7 @@ static int stedc_device(pg_ctx *ctx, int n, const double *d_in, const double *e_
             nblocks.push_back(s);
         }
         nblocks.push_back(n);
-        PG_HIP(hipMemcpyAsync(dnew.data(), wk.dnew, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        PG_HIP(hipMemcpyAsync(dnew, wk.dnew, (size_t)n * 8, hipMemcpyDeviceToHost, st));
         PG_HIP(hipStreamSynchronize(st));
         for (auto &mp : plans) {
             for (int i = 0; i < mp.k; i++) d[mp.s + i] = dnew[mp.s + i];
