@@ -751,9 +751,15 @@ static void plan_merge(MergePlan &mp, const double *d_in, const double *z_in, do
     const double sgn = (beta < 0.0) ? -1.0 : 1.0;
     for (int i = 0; i < nm; i++) z[i] = z_in[i] * ((i >= mp.n1) ? sgn : 1.0) * 0.7071067811865475244;
     mp.rho = 2.0 * fabs(beta);
+    // ascending order of the poles: sort (value, index) pairs — contiguous keys; equal values keep their index order, as a stable sort of
+    // the indices would (this runs on the host between two launches: ~0.5 ms of idle GPU per top-level merge with the indirect sort)
     std::vector<int> idx(nm);
-    std::iota(idx.begin(), idx.end(), 0);
-    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return d[a] < d[b]; });
+    {
+        std::vector<std::pair<double, int>> key(nm);
+        for (int i = 0; i < nm; i++) key[i] = {d[i], i};
+        std::sort(key.begin(), key.end());
+        for (int i = 0; i < nm; i++) idx[i] = key[i].second;
+    }
     double dmax = 0.0, zmax = 0.0;
     for (int i = 0; i < nm; i++) { dmax = std::max(dmax, fabs(d[i])); zmax = std::max(zmax, fabs(z[i])); }
     const double tol = 8.0 * eps * std::max(dmax, zmax);
@@ -773,7 +779,7 @@ static void plan_merge(MergePlan &mp, const double *d_in, const double *z_in, do
             if (mp.rho * fabs(z[nj]) <= tol) { defl_cols.push_back(nj); mp.ddefl.push_back(d[nj]); continue; }
             if (pj < 0) { pj = nj; continue; }
             double s_ = z[pj], c_ = z[nj];
-            const double tau = hypot(c_, s_), t = d[nj] - d[pj];
+            const double tau = sqrt(c_ * c_ + s_ * s_), t = d[nj] - d[pj];      // |z| <= 1 here (unit vectors' components): no need for hypot's range care
             c_ /= tau; s_ = -s_ / tau;
             if (fabs(t * c_ * s_) <= tol) {
                 z[nj] = tau; z[pj] = 0.0;
