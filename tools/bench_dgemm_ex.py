@@ -36,7 +36,10 @@ for m in (9984, 7424, 4992, 2560):
 for m in (9936, 4992):
     bench(f"Q1 W = V'Z   (256 x 10000)             K={m}", TA, 0, 256, 10000, m, 0.0, 10000, 10000, 10000, (m, 10000), (m, 10000), (256, 10000), 2.0 * 256 * 10000 * m)
     bench(f"Q1 Z -= V W2 ({m} x 10000)            K=256", 0, 0, m, 10000, 256, 1.0, 10000, 10000, 10000, (m, 10000), (256, 10000), (m, 10000), 2.0 * 256 * 10000 * m)
+for m in (9936, 4992):      # the same product with V handed over transposed (k-major A): is the m-major operand the slower one?
+    bench(f"Q1 Z -= Vt' W2 ({m} x 10000), A k-major  K=256", TA, 0, m, 10000, 256, 1.0, m, 10000, 10000, (256, m), (256, 10000), (m, 10000), 2.0 * 256 * 10000 * m)
 bench("square 8192^3", 0, 0, 8192, 8192, 8192, 0.0, 8192, 8192, 8192, (8192, 8192), (8192, 8192), (8192, 8192), 2.0 * 8192 ** 3)
+bench("square 8192^3, A k-major", TA, 0, 8192, 8192, 8192, 0.0, 8192, 8192, 8192, (8192, 8192), (8192, 8192), (8192, 8192), 2.0 * 8192 ** 3)
 bench("D&C merge  Q(10000x5000) U(5000x5000)", 0, 0, 10000, 5000, 5000, 0.0, 5000, 5000, 5000, (10000, 5000), (5000, 5000), (10000, 5000), 2.0 * 10000 * 5000 * 5000)
 bench("Gram  P'P (64x64)                      K=9936", TA, 0, 64, 64, 9936, 0.0, 10000, 10000, 64, (9936, 10000), None, (64, 64), 2.0 * 64 * 64 * 9936)
 bench("thin  Q = P R^-1 (9936x64)             K=64", 0, 0, 9936, 64, 64, 0.0, 10000, 64, 64, (9936, 10000), (64, 64), (9936, 64), 2.0 * 9936 * 64 * 64)
