@@ -1663,7 +1663,8 @@ __global__ __launch_bounds__(64 * NWT) void bc_stationary_kernel(int n, double *
             __builtin_amdgcn_raw_buffer_store_b128(mb_pack(vcur[lane], tag), rmail, (unsigned)(K * MB_LD * 8 + 16 * (MB_V + lane)), 0, BC_SC1);
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(mb_pack(tau, tag), rmail, (unsigned)(K * MB_LD * 8 + 16 * MB_TAU), 0, BC_SC1);
         }
-        // ---- (3a), (4a) w = E'v, p = D v   (lane = column, wq = RW rows)
+        // ---- (3a), (4a) w = E'v, p = D v   (lane = column, wq = RW rows).  (r4: the right-apply's arrangement transposed — NW lanes per column,
+        // DPP sums, no partials — brings nothing here: 43.4 against 42.7 ms; the symmetric D is read from its lower triangle in two patterns.)
         {
             double sw = 0.0, sp = 0.0;
 #pragma unroll
