@@ -496,7 +496,13 @@ __global__ __launch_bounds__(256) void recon_kernel(const double *G2, const doub
 #pragma unroll
         for (int k = 0; k < B; k++) {
             const double wkk = readlane_d(m[k], k);
-            const double dk = (wkk >= 0.0) ? -1.0 : 1.0, pv = 1.0 - dk * wkk, rc = 1.0 / pv, sc = -dk * rc;
+            // 1 / pivot by v_rcp_f64 + two Newton steps (the pivot is 1 + |w_kk| in [1, 2]): the IEEE division is ~300 dependent cycles, once per
+            // step of a chain of 64 (r4: 7 of this kernel's 71 us)
+            const double dk = (wkk >= 0.0) ? -1.0 : 1.0, pv = 1.0 - dk * wkk;
+            double rc = __builtin_amdgcn_rcp(pv);
+            rc = fma(rc, fma(-pv, rc, 1.0), rc);
+            rc = fma(rc, fma(-pv, rc, 1.0), rc);
+            const double sc = -dk * rc;
             if (lane == 0) { Dg[k] = dk; piv[k] = pv; prc[k] = rc; }
             const double l = (lane > k) ? m[k] * sc : 0.0;       // L[lane][k]
 #pragma unroll
