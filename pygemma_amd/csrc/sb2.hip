@@ -2188,14 +2188,13 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
                 }
             }
             if (kt + 1 < NA) lstoreA(buf ^ 1, (kt + 1) & 1);
+            else lstoreB(0, 0);        // the first chunk of the second product takes the buffer the step before last released: no barrier of its own
             __syncthreads();
         }
-#pragma unroll
-        for (int I = 0; I < 4; I++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) Ws[(I * 16 + rsub + 4 * e) * BT2_ZP + colw] = accA[I][e];
-        lstoreB(0, 0);
-        __syncthreads();
+        // W = V'Z stays in the accumulators: the C layout of v_mfma_f64_16x16x4 (lane (r, c): rows r + 4 e of column c) IS the B layout of the next
+        // product's k-step 4 e (row 4 e + r of column c), so accA[kt][kk / 4] is the operand — no trip through LDS, no barrier (r3-r4: W was
+        // written to LDS, 41 KB, and read back once per k-step)
+        static_assert(BT2_CK == 16, "accA[kt] = the 16 reflectors of chunk kt");
 #pragma unroll
         for (int kt = 0; kt < NB2; kt++) {
             const int buf = kt & 1;
@@ -2203,7 +2202,7 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
 #pragma unroll
             for (int kk = 0; kk < CK; kk += 4) {
                 const int kr = kk + rsub;
-                const double b2 = Ws[(kt * CK + kr) * BT2_ZP + colw];
+                const double b2 = accA[kt][kk / 4];
 #pragma unroll
                 for (int R = 0; R < 8; R++) {
                     if (kt < R - 4) continue;
