@@ -2075,6 +2075,13 @@ struct Bt2SArgs {
     double *Z;
     int vec;
 };
+#ifdef PG_BT2_TIME       // tools/bt2_time.py: s_memtime of workgroup (slab 10, first super-block) at the phase boundaries; what is read back is the LAST launch's
+                         // (one block per trip, the chip nearly empty: a workgroup alone on its CU)
+__device__ long long g_bt2_time[16];
+#define BT2_T(ix) do { if (blockIdx.x == 10 && blockIdx.y == 0 && threadIdx.x == 0) g_bt2_time[ix] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BT2_T(ix) do { } while (0)
+#endif
 __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
 {
     extern __shared__ double lds[];
@@ -2099,6 +2106,7 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
     const bool vec = ar.vec && ncols == BT2_NS;
     constexpr int SP2 = BT2_NS + 8;
     auto row_ok = [&](int r) { const long long g = slab0 + r; return r >= rlo && r < rhi && g >= 0 && g < n; };
+    BT2_T(0);
     if (vec) {
 #pragma unroll
         for (int half = 0; half < 2; half++) {
@@ -2195,6 +2203,7 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
         // product's k-step 4 e (row 4 e + r of column c), so accA[kt][kk / 4] is the operand — no trip through LDS, no barrier (r3-r4: W was
         // written to LDS, 41 KB, and read back once per k-step)
         static_assert(BT2_CK == 16, "accA[kt] = the 16 reflectors of chunk kt");
+        if (T0 == 4 && V == ar.Vp + ((size_t)k0 * (size_t)ar.ng + Ghi) * BLK) BT2_T(8);      // first block: end of the first product
 #pragma unroll
         for (int kt = 0; kt < NB2; kt++) {
             const int buf = kt & 1;
@@ -2214,10 +2223,15 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
         }
     };
     const size_t ngs = (size_t)ar.ng;
+    BT2_T(1);
     if (e0) apply(std::integral_constant<int, 4>{}, ar.Vp + ((size_t)k0 * ngs + Ghi) * BLK, ar.Vtp + ((size_t)k0 * ngs + Ghi) * BLK);
+    BT2_T(2);
     if (e1) apply(std::integral_constant<int, 8>{}, ar.Vp + ((size_t)(k0 + 1) * ngs + Ghi) * BLK, ar.Vtp + ((size_t)(k0 + 1) * ngs + Ghi) * BLK);
+    BT2_T(3);
     if (e2) apply(std::integral_constant<int, 0>{}, ar.Vp + ((size_t)k0 * ngs + Glo) * BLK, ar.Vtp + ((size_t)k0 * ngs + Glo) * BLK);
+    BT2_T(4);
     if (e3) apply(std::integral_constant<int, 4>{}, ar.Vp + ((size_t)(k0 + 1) * ngs + Glo) * BLK, ar.Vtp + ((size_t)(k0 + 1) * ngs + Glo) * BLK);
+    BT2_T(6);
     // ---- slab out
     if (vec) {
 #pragma unroll
@@ -2244,6 +2258,7 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
                 if (row_ok(row) && colw < ncols) Zg[(size_t)(slab0 + row) * n + colw] = zr[R][e];
             }
     }
+    BT2_T(7);
 }
 
 // the blocks (V, V T) of every (group, block index): needs only the reflectors, so the caller may run it on a second stream beside the
@@ -2362,5 +2377,12 @@ extern "C" int pgx_bcs_time(long long *out12, int reset)
 {
     if (reset) { long long z[12] = {0}; return hipMemcpyToSymbol(HIP_SYMBOL(pg::g_bcs_time), z, sizeof(z)) == hipSuccess ? 0 : -1; }
     return hipMemcpyFromSymbol(out12, HIP_SYMBOL(pg::g_bcs_time), sizeof(long long) * 12) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#ifdef PG_BT2_TIME
+extern "C" int pgx_bt2_time(long long *out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(pg::g_bt2_time), sizeof(long long) * 16) == hipSuccess ? 0 : -1;
 }
 #endif
