@@ -2292,13 +2292,15 @@ int bt2_device(pg_ctx *ctx, int n, double *Z, Sb2Work &w, bool prepared)
     if (const char *e_ = getenv("PG_BT2_FOUR")) four = atoi(e_) != 0;
     if (four) {
         const int nu = (ng + 1) / 2, kcount = (n - 1 + B - 1) / B, nks = (kcount + 1) / 2;
+        const int lds_pad = getenv("PG_BT2_LDS_PAD") ? atoi(getenv("PG_BT2_LDS_PAD")) : 0;      // A/B: > 6 KB leaves room for ONE workgroup per CU only
+        if (lds_pad > 0) PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bt2_apply4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BT2_LDS_BYTES + lds_pad));
         for (int ts = 0; ts <= (nu - 1) + (nks - 1); ts++) {
             const int u_lo = std::max(0, ts - (nks - 1)), u_hi = std::min(ts, nu - 1);
             Bt2SArgs ar;
             ar.n = n; ar.ng = ng; ar.ts = ts; ar.u_first = u_lo; ar.Vp = w.Vp; ar.Vtp = w.Vtp; ar.Z = Z;
             ar.vec = ((n & 1) == 0 && (uintptr_t)Z % 16 == 0) ? 1 : 0;
             if (const char *e_ = getenv("PG_BT2_VEC")) ar.vec = ar.vec && atoi(e_) != 0;      // A/B: 0 = the slab straight between memory and the MFMA layout
-            bt2_apply4_kernel<<<dim3(nslab, u_hi - u_lo + 1), 256, BT2_LDS_BYTES, st>>>(ar);
+            bt2_apply4_kernel<<<dim3(nslab, u_hi - u_lo + 1), 256, BT2_LDS_BYTES + lds_pad, st>>>(ar);
         }
         PG_HIP(hipGetLastError());
         return PG_OK;
