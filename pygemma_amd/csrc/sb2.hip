@@ -2142,19 +2142,23 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
     // one block on the row tiles T0 .. T0 + 7 of the slab registers (the body of bt2_apply_kernel).  Operand chunks are fetched TWO
     // steps ahead (a step is 8 - 16 MFMAs, 0.2 - 0.4 us: less than an L2 round trip), the first two chunks of the second product
     // during the last two steps of the first.
-    auto apply = [&](auto T0C, const double *V, const double *Vt) {
+    // The first two chunks of the NEXT block are asked for during the last two steps of the current one (the staging registers of the first
+    // product are idle by then): a block no longer starts with an exposed round trip to L2.
+    double2 stg[2][CK / 8];
+    bool prefetched = false;
+    auto apply = [&](auto T0C, const double *V, const double *Vt, const double *Vnext) {
         constexpr int T0 = decltype(T0C)::value;
         doublex4 accA[4];
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int e = 0; e < 4; e++) accA[i][e] = 0.0;
-        double2 stg[2][CK / 8];
         double rt[2][CK / 8][4];
-        auto gloadA = [&](int kt, int set) {
+        auto gloadAp = [&](const double *Vp_, int kt, int set) {
 #pragma unroll
-            for (int ps = 0; ps < CK / 8; ps++) stg[set][ps] = *reinterpret_cast<const double2 *>(V + (size_t)kt * CK * SB_G + 2 * (ps * 256 + tid));
+            for (int ps = 0; ps < CK / 8; ps++) stg[set][ps] = *reinterpret_cast<const double2 *>(Vp_ + (size_t)kt * CK * SB_G + 2 * (ps * 256 + tid));
         };
+        auto gloadA = [&](int kt, int set) { gloadAp(V, kt, set); };
         auto lstoreA = [&](int buf, int set) {
 #pragma unroll
             for (int ps = 0; ps < CK / 8; ps++) {
@@ -2177,8 +2181,7 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
 #pragma unroll
                 for (int q = 0; q < 4; q++) As[(buf * CK + ps * 8 + (tid & 1) * 4 + q) * BT2_AP + (tid >> 1)] = rt[set][ps][q];
         };
-        gloadA(0, 0);
-        gloadA(1, 1);
+        if (!prefetched) { gloadA(0, 0); gloadA(1, 1); }
         lstoreA(0, 0);
         __syncthreads();
 #pragma unroll
@@ -2208,6 +2211,7 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
         for (int kt = 0; kt < NB2; kt++) {
             const int buf = kt & 1;
             if (kt + 2 < NB2) gloadB(kt + 2, kt & 1);
+            else if (Vnext) gloadAp(Vnext, kt + 2 - NB2, kt + 2 - NB2);
 #pragma unroll
             for (int kk = 0; kk < CK; kk += 4) {
                 const int kr = kk + rsub;
@@ -2221,16 +2225,25 @@ __global__ __launch_bounds__(256, 2) void bt2_apply4_kernel(Bt2SArgs ar)
             if (kt + 1 < NB2) lstoreB(buf ^ 1, (kt + 1) & 1);
             __syncthreads();
         }
+        prefetched = Vnext != nullptr;
     };
     const size_t ngs = (size_t)ar.ng;
     BT2_T(1);
-    if (e0) apply(std::integral_constant<int, 4>{}, ar.Vp + ((size_t)k0 * ngs + Ghi) * BLK, ar.Vtp + ((size_t)k0 * ngs + Ghi) * BLK);
-    BT2_T(2);
-    if (e1) apply(std::integral_constant<int, 8>{}, ar.Vp + ((size_t)(k0 + 1) * ngs + Ghi) * BLK, ar.Vtp + ((size_t)(k0 + 1) * ngs + Ghi) * BLK);
-    BT2_T(3);
-    if (e2) apply(std::integral_constant<int, 0>{}, ar.Vp + ((size_t)k0 * ngs + Glo) * BLK, ar.Vtp + ((size_t)k0 * ngs + Glo) * BLK);
-    BT2_T(4);
-    if (e3) apply(std::integral_constant<int, 4>{}, ar.Vp + ((size_t)(k0 + 1) * ngs + Glo) * BLK, ar.Vtp + ((size_t)(k0 + 1) * ngs + Glo) * BLK);
+    {
+        const double *Vb[4] = {ar.Vp + ((size_t)k0 * ngs + Ghi) * BLK, ar.Vp + ((size_t)(k0 + 1) * ngs + Ghi) * BLK, ar.Vp + ((size_t)k0 * ngs + Glo) * BLK,
+                               ar.Vp + ((size_t)(k0 + 1) * ngs + Glo) * BLK};
+        const double *Tb[4] = {ar.Vtp + ((size_t)k0 * ngs + Ghi) * BLK, ar.Vtp + ((size_t)(k0 + 1) * ngs + Ghi) * BLK, ar.Vtp + ((size_t)k0 * ngs + Glo) * BLK,
+                               ar.Vtp + ((size_t)(k0 + 1) * ngs + Glo) * BLK};
+        const bool ex[4] = {e0, e1, e2, e3};
+        auto next_of = [&](int q) -> const double * { for (int r = q + 1; r < 4; r++) if (ex[r]) return Vb[r]; return nullptr; };
+        if (e0) apply(std::integral_constant<int, 4>{}, Vb[0], Tb[0], next_of(0));
+        BT2_T(2);
+        if (e1) apply(std::integral_constant<int, 8>{}, Vb[1], Tb[1], next_of(1));
+        BT2_T(3);
+        if (e2) apply(std::integral_constant<int, 0>{}, Vb[2], Tb[2], next_of(2));
+        BT2_T(4);
+        if (e3) apply(std::integral_constant<int, 4>{}, Vb[3], Tb[3], nullptr);
+    }
     BT2_T(6);
     // ---- slab out
     if (vec) {
